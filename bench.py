@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bags/sec, forward + nll_surv + backward (all parameter grads materialised), path attention-MIL
+`small` (1024 -> 256 -> 256, gated, K=4), one 50k x 1024 synthetic bag per GPU per step.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = model(**bag) -> NLLSurvLoss -> backward through the drop-in module surface (the same calls
+utils/core_utils.py:200-243 of the reference makes), bag resident in HBM; N > 1 adds ONE RCCL
+all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == the reference's --gc N).
+Train mode as `model.train()` with --drop_out off (one Dropout(0.25) mask, the headline mode of
+BASELINE.md); rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32, dense)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bag", type=int, default=50000, help="instances per bag (BASELINE metric: 50000)")
+    ap.add_argument("--eval-mode", action="store_true", help="no dropout (secondary figure)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bags", type=int, default=8, help="timed bags of the CPU baseline sample")
+    ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
+    return ap.parse_args()
+
+
+def flops_per_bag(N, L=1024, H=256, D=256):
+    """Algorithmic FLOPs: fwd 2LH + 2*2HD + ..., bwd dW1 + dWab + dh."""
+    fwd = 2 * L * H + 2 * 2 * H * D + 2 * D + 2 * H
+    bwd = 2 * H * L + 2 * 2 * D * H + 2 * 2 * D * H + 2048
+    return (fwd + bwd) * N
+
+
+def bytes_per_bag(N, L=1024):
+    return 2 * 4 * L * N + 4 * N + 4.7e6
+
+
+def build_model(dev, eval_mode):
+    import torch
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    torch.manual_seed(1)
+    model = MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=False, n_classes=4)
+    model = model.to(dev)
+    model.eval() if eval_mode else model.train()
+    return model
+
+
+def make_step(model, x, dev, flat=None, world=1):
+    import torch
+    import torch.distributed as dist
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    loss_fn = NLLSurvLoss(alpha=0.0)
+    Y = torch.tensor([1], device=dev)
+    c = torch.tensor([0.0], device=dev)
+    inv = 1.0 / world
+
+    def step():
+        if flat is not None:
+            flat.zero_()
+        else:
+            for p in model.parameters():
+                p.grad = None
+        hazards, S, Y_hat, _ = model(path_features=x)
+        loss = loss_fn(hazards=hazards, S=S, Y=Y, c=c)
+        (loss * inv if world > 1 else loss).backward()
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)   # RCCL over xGMI: one collective per step
+        return loss
+
+    return step
+
+
+def time_steps(step, steps, warmup, world):
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_profile(step, steps):
+    """Per-kernel average duration from HIP events recorded on the launch stream (library hook)."""
+    import torch
+    from multimodalfusion_amd import _lib
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_dump()
+    _lib.profile_enable(False)
+    return {k: dict(launches=n, avg_us=1e3 * ms / max(n, 1)) for k, (n, ms) in prof.items()}
+
+
+def cpu_baseline(N, n_bags):
+    """The oracle's torch-CPU port (kind 'port'), same op sequence as the reference's CPU path, train mode
+    with the one always-on Dropout(0.25), fp32, all host cores.  Bounded sample: `n_bags` bags after 2 warm-up."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import inputs as gen
+    from oracle import torch_port as tp
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = tp.to_torch(gen.path_state_dict(seed=1, gated=True, size="small", n_classes=4), torch.float32)
+    x = torch.as_tensor(gen.bag(1234, N))
+    Y, c = torch.tensor([1]), torch.tensor([0.0])
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        hz, S, Yh, A, M = tp.path_forward(sd, x, True, False, masks="torch")
+        loss = tp.nll_loss(hz, S, Y, c, alpha=0.0)
+        loss.backward()
+
+    for _ in range(2):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(n_bags):
+        one()
+    dt = time.perf_counter() - t0
+    return dict(value=n_bags / dt, unit="bags/s", cores=cores, kind="port",
+                sample=f"{n_bags} bags of {N}x1024 fwd+nll_surv+bwd after 2 warm-up, fp32, train mode "
+                       f"(1 dropout mask), torch {torch.__version__} CPU, {cores} threads")
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    N = args.bag
+
+    model = build_model(dev, args.eval_mode)
+    flat = None
+    if world > 1:
+        # flat fp32 gradient buffer; every p.grad is a view into it, so backward accumulates in place and the
+        # step needs exactly one all-reduce
+        n_el = sum(p.numel() for p in model.parameters())
+        flat = torch.zeros(n_el, device=dev)
+        off = 0
+        for p in model.parameters():
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x = torch.randn(N, 1024, device=dev, generator=g)      # synthetic bag, resident in HBM
+    step = make_step(model, x, dev, flat, world)
+
+    dt = time_steps(step, args.steps, args.warmup, world)
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * args.steps / dt
+
+    out = {
+        "metric": "bags/sec fwd+bwd, path-AMIL 50k x 1024 synthetic bag" if N == 50000 else f"bags/sec fwd+bwd, path-AMIL {N} x 1024 synthetic bag",
+        "value": value, "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) bag per GPU per step, "
+                               f"nll_surv alpha=0, {'eval' if args.eval_mode else 'train (1 dropout mask)'} mode, "
+                               f"fwd+loss+bwd, grads materialised" + (", 1 RCCL all-reduce/step" if world > 1 else ""),
+                   "instances_per_bag": N, "parallelism": f"dp{world} (one bag per GPU)"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ----
+        prof = kernel_profile(step, max(5, min(args.steps, 20)))
+        dom = max(prof.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0] if prof else None
+        kflops = {
+            "linear_nt_kernel": 2 * 1024 * 256 * N,
+            "gate_fwd_kernel": 2 * 2 * 256 * 256 * N,
+            "bwd_dh_kernel": 2 * 2 * 256 * 256 * N,
+            "tn_kernel": (2 * 256 * 1024 + 2 * 2 * 256 * 256) * N,
+        }
+        if dom in kflops:
+            t_us = prof[dom]["avg_us"]
+            ach = kflops[dom] / (t_us * 1e-6) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
+        tot = flops_per_bag(N)
+        out["whole_step"] = {"tflops": tot / (ms_per_step * 1e-3) / 1e12,
+                             "frac_fp32_mfma_peak": tot / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             "algorithmic_gbs": bytes_per_bag(N) / (ms_per_step * 1e-3) / 1e9,
+                             "frac_hbm_peak": bytes_per_bag(N) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}
+        if args.extra_sizes and world == 1:
+            extra = {}
+            for n2 in (1000, 10000):
+                x2 = torch.randn(n2, 1024, device=dev, generator=g)
+                st2 = make_step(model, x2, dev, None, 1)
+                d2 = time_steps(st2, args.steps, args.warmup, 1)
+                extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": 1e3 * d2 / args.steps}
+            out["other_sizes"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

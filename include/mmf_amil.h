@@ -1,0 +1,130 @@
+/* mmf_amil.h -- C ABI of libmmf_amil.so: the MI355X (gfx950) attention-MIL + survival-loss hot path.
+ *
+ * The reference (MultimodalFusion/multimodalfusion) has no FFI / plugin API: its boundary is
+ * the Python nn.Module surface.  This header is the C ABI that sits directly beneath that
+ * surface -- the entry points a binding for this path binds (ctypes in this repo, see
+ * INTEGRATION.md).  Each entry point names the reference lines it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32, row-major, 16-byte aligned)
+ *     unless the comment says "host";  the library allocates nothing and keeps no state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), performs no host synchronisation, and is re-entrant / thread-safe (autograd
+ *     calls backward from another thread);
+ *   - return value: 0 on success, negative mmf error code otherwise (mmf_strerror()).
+ *   - "workspace": a caller-owned scratch buffer; forward fills it with the saved activations
+ *     (h, a, b, scores, softmax statistics) that backward reads, so the SAME buffer must be
+ *     passed to the matching backward call, unmodified in between.
+ */
+#ifndef MMF_AMIL_H
+#define MMF_AMIL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ACT_NONE 0
+#define MMF_ACT_RELU 1
+#define MMF_ACT_TANH 2
+#define MMF_ACT_SIGMOID 3
+#define MMF_ACT_SELU 4
+
+const char* mmf_strerror(int code);
+/* ABI version; bumped on any signature change. */
+int mmf_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention-MIL stack:  Sequential(Linear(L,H), ReLU, Dropout(0.25), Attn_Net[_Gated](H,D,1))
+ * followed by softmax pooling over the instances.
+ *   replaces models/model_attention_mil_path.py:20-29 (construction), :52-56 (forward),
+ *            models/model_modules.py:70-85 (Attn_Net), :87-110 (Attn_Net_Gated),
+ *            and the same stack in model_attention_mil_radio.py:88-99 / model_mm_attention_mil.py:146-160.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mmf_amil_desc {
+  int64_t N;          /* instances in the bag */
+  int32_t L, H, D;    /* feature dim, hidden dim, attention dim: small 1024/256/256, big 1024/512/384 */
+  int32_t gated;      /* 1 = Attn_Net_Gated, 0 = Attn_Net */
+  const float* W1;    /* [H x L]  attention_net.0.weight */
+  const float* b1;    /* [H] */
+  const float* Wa;    /* [D x H]  attention_a.0.weight (gated) / module.0.weight (ungated) */
+  const float* ba;    /* [D] */
+  const float* Wb;    /* [D x H]  attention_b.0.weight (gated only, else NULL) */
+  const float* bb;    /* [D] */
+  const float* Wc;    /* [1 x D]  attention_c.weight / module.{2|3}.weight */
+  const float* bc;    /* [1] */
+  float p_h;          /* dropout prob after the ReLU (0.25 in train mode, 0 in eval) */
+  float p_att;        /* dropout prob on the tanh / sigmoid branches (0.25 iff dropout=True and training) */
+  uint32_t seed;      /* dropout seed of this call; masks are regenerated, never stored */
+} mmf_amil_desc;
+
+typedef struct mmf_amil_grads {
+  float* dW1; float* db1;
+  float* dWa; float* dba;
+  float* dWb; float* dbb;   /* NULL when ungated */
+  float* dWc; float* dbc;
+  float* dx;                /* [N x L] or NULL (path bags need no input gradient; radio does) */
+} mmf_amil_grads;
+
+size_t mmf_amil_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated);
+
+/* x [N x L] -> M [H] (pooled embedding), A_raw [N] (pre-softmax scores, what heat-maps consume). */
+int mmf_amil_forward(const mmf_amil_desc* desc, const float* x, void* workspace, size_t workspace_bytes,
+                     float* M, float* A_raw, void* stream);
+
+/* dM [H], gA [N] (gradient w.r.t. A_raw, may be NULL) -> parameter grads (overwritten, not accumulated). */
+int mmf_amil_backward(const mmf_amil_desc* desc, const float* x, void* workspace, size_t workspace_bytes,
+                      const float* M, const float* A_raw, const float* dM, const float* gA,
+                      const mmf_amil_grads* grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layer on MFMA:  y = dropout(act(concat_k(x_0..x_{nseg-1}) . W^T + bias))
+ *   replaces torch.cat + nn.Linear of model_attention_mil_radio.py:80-82 (reduce_dim; the modality
+ *   bags are never concatenated in memory) and the instance projections generally.
+ *   x_segs: HOST array of nseg (<= 4) device pointers, each [M x kseg]; K = nseg*kseg; K % 32 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
+                       const float* W, const float* bias, int32_t N, int32_t act,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_site, float* y, void* stream);
+
+size_t mmf_linear_backward_workspace_bytes(int64_t M, int32_t N, int32_t K);
+/* dy [M x N] (gradient w.r.t. the pre-activation output) -> dW [N x K], db [N] (may be NULL),
+ * dx [M x K] single buffer (may be NULL; only nseg == 1). */
+int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
+                        const float* W, int32_t N, float* dW, float* db, float* dx,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Survival head:  logits = f.Wk^T + bk; hazards = sigmoid(logits); S = cumprod(1-hazards); Y_hat = argmax
+ *   replaces models/model_attention_mil_path.py:58-61.
+ * ------------------------------------------------------------------------------------------- */
+int mmf_surv_head_forward(const float* feat, const float* Wk, const float* bk, int32_t B, int32_t F, int32_t K,
+                          float* logits, float* hazards, float* S, int64_t* Y_hat, void* stream);
+int mmf_surv_head_backward(const float* g_hazards, const float* g_S, const float* hazards, const float* feat,
+                           const float* Wk, int32_t B, int32_t F, int32_t K,
+                           float* dfeat, float* dWk, float* dbk, void* stream);
+
+/* nll_surv loss (utils/loss_utils.py:22-39): loss [1], and its gradients g_hazards, g_S [B x K]. */
+int mmf_nll_surv(const float* hazards, const float* S, const int64_t* Y, const float* c, int32_t B, int32_t K,
+                 float alpha, float eps, float* loss, float* g_hazards, float* g_S, void* stream);
+
+/* Cox partial-likelihood loss (utils/loss_utils.py:124-139): loss [1], d_risks [B].  times is float64. */
+int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_t B,
+                 float* loss, float* d_risks, void* stream);
+
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
+ * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
+ * records and returns the number of bytes written (or needed when buf == NULL). */
+void mmf_profile_enable(int on);
+int mmf_profile_dump(char* buf, size_t buf_bytes);
+
+/* Host-side restatement of the device dropout keep-hash (1 = kept).  For tests / mask inspection only. */
+int mmf_dropout_keep_host(uint32_t seed, uint32_t site, uint32_t index, float p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMF_AMIL_H */

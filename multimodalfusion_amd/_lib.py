@@ -1,0 +1,134 @@
+"""ctypes binding of libmmf_amil.so (C ABI: include/mmf_amil.h).
+
+There is no CPU fallback: if the shared library is missing or a call is made with
+non-GPU tensors the functions raise.  The library itself is only *loaded* here (symbol
+resolution); no HIP call happens until an entry point is invoked.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmf_amil.so")
+
+ABI_VERSION = 1
+
+c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+
+
+class AmilDesc(C.Structure):
+    """struct mmf_amil_desc (include/mmf_amil.h)."""
+    _fields_ = [
+        ("N", C.c_int64), ("L", C.c_int32), ("H", C.c_int32), ("D", C.c_int32), ("gated", C.c_int32),
+        ("W1", C.c_void_p), ("b1", C.c_void_p), ("Wa", C.c_void_p), ("ba", C.c_void_p),
+        ("Wb", C.c_void_p), ("bb", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
+        ("p_h", C.c_float), ("p_att", C.c_float), ("seed", C.c_uint32),
+    ]
+
+
+class AmilGrads(C.Structure):
+    """struct mmf_amil_grads (include/mmf_amil.h)."""
+    _fields_ = [
+        ("dW1", C.c_void_p), ("db1", C.c_void_p), ("dWa", C.c_void_p), ("dba", C.c_void_p),
+        ("dWb", C.c_void_p), ("dbb", C.c_void_p), ("dWc", C.c_void_p), ("dbc", C.c_void_p),
+        ("dx", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/mmf_amil.h declares
+SYMBOLS = {
+    "mmf_strerror": (C.c_char_p, [C.c_int]),
+    "mmf_abi_version": (C.c_int, []),
+    "mmf_amil_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "mmf_amil_forward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_amil_backward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(AmilGrads), C.c_void_p]),
+    "mmf_linear_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mmf_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "mmf_linear_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mmf_surv_head_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_surv_head_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_nll_surv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                               C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_cox_surv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_dropout_keep_host": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
+    "mmf_profile_enable": (None, [C.c_int]),
+    "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),
+}
+
+
+def profile_enable(on: bool):
+    lib().mmf_profile_enable(1 if on else 0)
+
+
+def profile_dump():
+    """{kernel_name: (launches, total_ms)} since the last dump (HIP events on the launch stream)."""
+    l = lib()
+    buf = C.create_string_buffer(1 << 16)     # one call: the dump clears the records
+    l.mmf_profile_dump(buf, 1 << 16)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+_lib = None
+
+
+class MmfError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libmmf_amil.so once; raise loudly if it is missing (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MmfError(
+                f"{LIB_PATH} not found: the HIP extension has not been built. "
+                "Run `python -m multimodalfusion_amd.build` (needs hipcc, gfx950 target). "
+                "There is no CPU fallback for the attention-MIL path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        v = l.mmf_abi_version()
+        if v != ABI_VERSION:
+            raise MmfError(f"libmmf_amil.so ABI version {v}, binding expects {ABI_VERSION}: rebuild")
+        _lib = l
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().mmf_strerror(code).decode()
+        raise MmfError(f"{what} failed: {msg} (code {code})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int64/fp64 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MmfError("multimodalfusion_amd ops need tensors on the MI355X (device 'cuda'); "
+                       "there is no CPU path -- call model.relocate() / .to('cuda') first")
+    if not t.is_contiguous():
+        raise MmfError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

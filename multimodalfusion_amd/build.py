@@ -1,0 +1,70 @@
+"""Builds libmmf_amil.so (HIP kernels + C ABI) for gfx950, in-tree, with plain hipcc.
+
+    python -m multimodalfusion_amd.build [--force] [--keep-temps]
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmmf_amil.so")
+OBJ = os.path.join(HERE, "_build")   # objects and -save-temps output (git- and gpurun-ignored)
+SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
+HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h",
+           os.path.join("..", "..", "include", "mmf_amil.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -> str:
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    jobs = []
+    os.makedirs(OBJ, exist_ok=True)
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if keep_temps:
+                cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            jobs.append(cmd)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
+        return cmd, r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for cmd, r in ex.map(run, jobs):
+                if verbose and (r.returncode != 0 or keep_temps):
+                    sys.stderr.write(r.stderr)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stderr[-4000:])
+    if jobs or force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: " + r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, keep_temps="--keep-temps" in sys.argv)
+    print(path)

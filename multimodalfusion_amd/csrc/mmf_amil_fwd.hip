@@ -1,0 +1,355 @@
+// Forward kernels of the attention-MIL stack on MI355X (gfx950).
+//
+//   K-lin   y = drop(act(x.W^T + b))                 models/model_attention_mil_path.py:20-21 (Linear+ReLU+Dropout)
+//                                                    models/model_attention_mil_radio.py:80-82 (cat + reduce_dim)
+//   K-gate  a = tanh(h.Wa^T+ba), b = sigmoid(h.Wb^T+bb), s_part = sum_d a.b.Wc   models/model_modules.py:105-110 (gated)
+//           a = tanh(h.Wa^T+ba),                          s_part = sum_d a.Wc     models/model_modules.py:73-85  (ungated)
+//   K-pool  A_raw = sum(s_part)+bc ; per-group online-softmax partials (max, sum e, sum e.h)
+//   K-merge M = softmax(A_raw).h, (max, denom)        models/model_attention_mil_path.py:53-56
+#include "mmf_gemm_core.h"
+#include "mmf_kernels.h"
+
+namespace mmf {
+
+// =============================================================================================
+// K-lin : NT GEMM + bias + activation + dropout
+// =============================================================================================
+__device__ inline float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_TANH: return fast_tanh(v);
+    case ACT_SIGMOID: return fast_sigmoid(v);
+    case ACT_SELU: {
+      const float alpha = 1.6732632423543772f, scale = 1.0507009873554805f;
+      return scale * (v > 0.f ? v : alpha * (__expf(v) - 1.0f));
+    }
+    default: return v;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, col0 = nt * T::BN;
+
+  LoadK<T::BM, T::NT> la;
+  la.init_segments(p.x, p.nseg, p.kseg, p.ldx, row0, (int)p.M);
+  LoadK<T::BN, T::NT> lb;
+  lb.init(p.w, p.K, col0, p.N);
+
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+
+  const uint32_t thr = drop_threshold(p.drop_p);
+  const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  for_each_c<T>(acc, [&](int r, int c, float v) {
+    int row = row0 + r, col = col0 + c;
+    if (row < p.M && col < p.N) {
+      float y = v + (p.bias ? p.bias[col] : 0.f);
+      y = apply_act(y, p.act);
+      if (p.drop_p > 0.f) y = keep(p.drop_key, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, thr) ? y * scale : 0.f;
+      p.y[(size_t)row * p.N + col] = y;
+    }
+  });
+}
+
+// =============================================================================================
+// K-gate : NT GEMM of h against an interleaved [Wa-block | Wb-block] tile, fused gate epilogue
+// =============================================================================================
+// B-operand loader: tile row j -> 32-row block jb = j/32.  Gated: blocks alternate a, b for the
+// same 32 attention dims, so a wave's (nb = 2t, 2t+1) accumulators hold the tanh- and the
+// sigmoid-branch pre-activations of the SAME (instance, d) in the SAME lane and register.
+template <int ROWS, int NT, bool GATED>
+struct LoadGateW {
+  using Map = KMap<ROWS, NT>;
+  const float *Wa, *Wb;
+  int H, D, d0, tid;
+  float4 r[Map::NV];
+  __device__ inline void init(const float* wa, const float* wb, int H_, int D_, int d0_) {
+    Wa = wa; Wb = wb; H = H_; D = D_; d0 = d0_; tid = threadIdx.x;
+  }
+  // With NT == 256 vector slot i of the k-contiguous map is exactly 32-row block i
+  // (row = tid/8 + 32 i), so the branch (a|b) of a slot is a compile-time property of i.
+  static_assert(NT == 256 && Map::EXACT, "LoadGateW assumes 256 threads");
+  __device__ inline void load(int kt) {
+    const int w = tid >> 3, c = 4 * (tid & 7);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int d;
+      const float* W;
+      if (GATED) { d = d0 + (i >> 1) * 32 + w; W = (i & 1) ? Wb : Wa; }
+      else       { d = d0 + i * 32 + w; W = Wa; }
+      int dc = d < D ? d : D - 1;
+      r[i] = ld4(W + (size_t)dc * H + kt * KC + c);
+    }
+  }
+  __device__ inline void store(float* lds) const {
+    const int w = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int d = GATED ? d0 + (i >> 1) * 32 + w : d0 + i * 32 + w;
+      st4(lds + Map::lds(tid, i), d < D ? r[i] : zero4());
+    }
+  }
+};
+
+template <class T, bool GATED>
+__global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int DT = GATED ? T::BN / 2 : T::BN;   // attention dims covered by one tile
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, d0 = nt * DT;
+
+  LoadK<T::BM, T::NT> la;
+  la.init(p.h, p.H, row0, (int)p.N);
+  LoadGateW<T::BN, T::NT, GATED> lb;
+  lb.init(p.Wa, p.Wb, p.H, p.D, d0);
+
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
+
+  // ---- epilogue: activations, stores, per-row partial score -----------------------------
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int r = lane & 31, hh = lane >> 5;
+  const uint32_t thr = drop_threshold(p.drop_p);
+  const bool drop = p.drop_p > 0.f;
+  const float dscale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  float* sred = lds;   // [WN][BM] row partials; the main loop's last barrier has retired all LDS reads
+
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb) {
+    float rowsum[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rowsum[i] = 0.f;
+    if constexpr (GATED) {
+#pragma unroll
+      for (int t = 0; t < T::NB / 2; ++t) {
+        const int d = d0 + (wn * (T::NB / 2) + t) * 32 + r;
+        const bool dok = d < p.D;
+        const float bav = dok ? p.ba[d] : 0.f, bbv = dok ? p.bb[d] : 0.f, wc = dok ? p.Wc[d] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = row0 + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          float av = fast_tanh(acc[mb][2 * t][i] + bav);
+          float bv = fast_sigmoid(acc[mb][2 * t + 1][i] + bbv);
+          if (row < p.N && dok) {
+            size_t o = (size_t)row * p.D + d;
+            p.a[o] = av;
+            p.b[o] = bv;
+            if (drop) {
+              uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
+              av = keep(p.key_a, idx, thr) ? av * dscale : 0.f;
+              bv = keep(p.key_b, idx, thr) ? bv * dscale : 0.f;
+            }
+            rowsum[i] += av * bv * wc;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < T::NB; ++nb) {
+        const int d = d0 + (wn * T::NB + nb) * 32 + r;
+        const bool dok = d < p.D;
+        const float bav = dok ? p.ba[d] : 0.f, wc = dok ? p.Wc[d] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = row0 + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          float av = fast_tanh(acc[mb][nb][i] + bav);
+          if (row < p.N && dok) {
+            p.a[(size_t)row * p.D + d] = av;
+            if (drop) av = keep(p.key_a, (uint32_t)row * (uint32_t)p.D + (uint32_t)d, thr) ? av * dscale : 0.f;
+            rowsum[i] += av * wc;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = half_sum(rowsum[i]);
+      if (r == 0) sred[wn * T::BM + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < T::BM; i += T::NT) {
+    int row = row0 + i;
+    if (row < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < T::WN; ++w) s += sred[w * T::BM + i];
+      p.s_part[(size_t)nt * p.N + row] = s;
+    }
+  }
+}
+
+// =============================================================================================
+// K-pool : scores + per-group online-softmax partials.  HBM-bound (reads h once).
+// =============================================================================================
+constexpr int POOL_MAX_ROWS = 8192;
+
+__global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
+  __shared__ float s_lds[POOL_MAX_ROWS];
+  __shared__ float red[256];
+  __shared__ __align__(16) float vred[1024];   // RG * VPR == 256 float4 slots
+  const int tid = threadIdx.x, g = blockIdx.x;
+  const int64_t r0 = (int64_t)g * p.rows_per_group;
+  const int64_t r1 = r0 + p.rows_per_group < p.N ? r0 + p.rows_per_group : p.N;
+  const int nrows = r1 > r0 ? (int)(r1 - r0) : 0;
+  const float bc = p.bc ? p.bc[0] : 0.f;
+
+  float lmax = -INFINITY;
+  for (int i = tid; i < nrows; i += 256) {
+    float s = bc;
+    for (int t = 0; t < p.n_parts; ++t) s += p.s_part[(size_t)t * p.N + r0 + i];
+    p.A_raw[r0 + i] = s;
+    s_lds[i] = s;
+    lmax = fmaxf(lmax, s);
+  }
+  lmax = wave_max(lmax);
+  if ((tid & 63) == 0) red[tid >> 6] = lmax;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+
+  const int VPR = p.H / 4;          // float4 per row: 64 (H=256), 128 (H=512), 256 (H=1024)
+  const int RG = 256 / VPR;         // row groups processed concurrently
+  const int cv = tid % VPR, rg = tid / VPR;
+  float4 v = zero4();
+  float lsum = 0.f;
+  for (int i = rg; i < nrows; i += RG) {
+    float e = __expf(s_lds[i] - m);
+    float4 hv = ld4(p.h + (size_t)(r0 + i) * p.H + 4 * cv);
+    v.x += e * hv.x; v.y += e * hv.y; v.z += e * hv.z; v.w += e * hv.w;
+    if (cv == 0) lsum += e;
+  }
+  st4(vred + (rg * VPR + cv) * 4, v);
+  if (cv == 0) red[rg] = lsum;
+  __syncthreads();
+  float* out = p.partials + (size_t)g * (2 + p.H);
+  if (tid < VPR) {
+    float4 s = zero4();
+    for (int q = 0; q < RG; ++q) {
+      float4 t = ld4(vred + (q * VPR + tid) * 4);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    out[2 + 4 * tid + 0] = s.x; out[2 + 4 * tid + 1] = s.y;
+    out[2 + 4 * tid + 2] = s.z; out[2 + 4 * tid + 3] = s.w;
+  }
+  if (tid == 0) {
+    float l = 0.f;
+    for (int q = 0; q < RG; ++q) l += red[q];
+    out[0] = nrows > 0 ? m : -INFINITY;
+    out[1] = l;
+  }
+}
+
+// single workgroup: merge the per-group partials
+__global__ __launch_bounds__(256) void pool_merge_kernel(PoolParams p) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int g = tid; g < p.n_groups; g += 256) m = fmaxf(m, p.partials[(size_t)g * (2 + p.H)]);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float l = 0.f;
+  for (int g = tid; g < p.n_groups; g += 256) {
+    const float* q = p.partials + (size_t)g * (2 + p.H);
+    float mg = q[0];
+    if (mg > -INFINITY) l += q[1] * __expf(mg - m);
+  }
+  l = wave_sum(l);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = l;
+  __syncthreads();
+  l = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.0f / l;
+  for (int c = tid; c < p.H; c += 256) {
+    float acc = 0.f;
+    for (int g = 0; g < p.n_groups; ++g) {
+      const float* q = p.partials + (size_t)g * (2 + p.H);
+      float mg = q[0];
+      if (mg > -INFINITY) acc += q[2 + c] * __expf(mg - m);
+    }
+    p.M[c] = acc * inv;
+  }
+  if (tid == 0) { p.stats[0] = m; p.stats[1] = l; }
+}
+
+// =============================================================================================
+// host launchers
+// =============================================================================================
+template <class T, class P>
+static int launch_tiled(const char* name, void (*kern)(P), const P& p, int grid, hipStream_t st) {
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES)) return e;
+  ProfScope ps(name, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), T::LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+using TileNT128 = Tile<128, 128, 2, 2, true, true>;
+using TileNT64 = Tile<64, 64, 2, 2, true, true>;
+
+// rows-per-tile choice: big tiles once there is enough work to fill 256 CUs twice over
+static inline bool use_big_tiles(int64_t M, int N) { return (M / 128) * ((N + 127) / 128) >= 256; }
+
+int launch_linear(LinearParams p, hipStream_t st) {
+  if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
+  if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
+  if (p.M <= 0) return MMF_OK;
+  if (use_big_tiles(p.M, p.N)) {
+    p.mt_count = (int)((p.M + 127) / 128); p.nt_count = (p.N + 127) / 128;
+    return launch_tiled<TileNT128>("linear_nt_kernel", linear_nt_kernel<TileNT128>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  }
+  p.mt_count = (int)((p.M + 63) / 64); p.nt_count = (p.N + 63) / 64;
+  return launch_tiled<TileNT64>("linear_nt_kernel", linear_nt_kernel<TileNT64>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+}
+
+int gate_parts(int D, int gated, int64_t N) {
+  (void)N;
+  // one s_part row per attention-dim tile; tile width must match launch_gate_fwd()
+  return gated ? (D + 63) / 64 : (D + 127) / 128;
+}
+
+int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
+  if (p.H % KC != 0 || p.D % 32 != 0) return MMF_ERR_SHAPE;
+  if (p.N <= 0) return MMF_OK;
+  // BN = 128 always (64 gated dims, or 128 ungated dims, per tile) so that gate_parts() is size independent
+  p.nt_count = gate_parts(p.D, p.gated, p.N);
+  const bool big = (p.N / 128) * p.nt_count >= 256;
+  if (big) {
+    p.mt_count = (int)((p.N + 127) / 128);
+    int grid = grid_for_tiles(p.mt_count, p.nt_count);
+    return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, true>, p, grid, st)
+                   : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, false>, p, grid, st);
+  }
+  using TS = Tile<64, 128, 2, 2, true, true>;
+  p.mt_count = (int)((p.N + 63) / 64);
+  int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  return p.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, p, grid, st)
+                 : launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, false>, p, grid, st);
+}
+
+int pool_groups(int64_t N) {
+  int64_t g = (N + 63) / 64;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  while ((N + g - 1) / g > POOL_MAX_ROWS) g *= 2;
+  return (int)g;
+}
+
+int launch_pool(PoolParams p, hipStream_t st) {
+  if (p.H != 256 && p.H != 512 && p.H != 1024) return MMF_ERR_SHAPE;
+  p.n_groups = pool_groups(p.N);
+  p.rows_per_group = (int)((p.N + p.n_groups - 1) / p.n_groups);
+  if (p.rows_per_group > POOL_MAX_ROWS) return MMF_ERR_SHAPE;
+  { ProfScope ps("pool_partial_kernel", st); hipLaunchKernelGGL(pool_partial_kernel, dim3(p.n_groups), dim3(256), 0, st, p); }
+  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(1), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+}  // namespace mmf

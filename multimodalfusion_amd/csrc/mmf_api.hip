@@ -1,0 +1,375 @@
+// C ABI (include/mmf_amil.h): argument checks, workspace carving, kernel sequencing.
+// No allocation, no host synchronisation, no global mutable state except the (mutex-guarded)
+// "dynamic LDS attribute already set" set.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/mmf_amil.h"
+#include "mmf_common.h"
+#include "mmf_gemm_core.h"
+#include "mmf_kernels.h"
+#include "mmf_small.h"
+
+namespace mmf {
+
+int set_dyn_lds(const void* kern, int bytes) {
+  if (bytes <= 48 * 1024) return MMF_OK;
+  static std::mutex mu;
+  static std::unordered_set<const void*> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(kern)) return MMF_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return MMF_ERR_LAUNCH;
+  done.insert(kern);
+  return MMF_OK;
+}
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static bool g_prof_on = false;
+
+void prof_begin(const char* name, hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  ProfRec r{name, nullptr, nullptr};
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+}
+void prof_end(hipStream_t st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (!g_prof.empty()) hipEventRecord(g_prof.back().b, st);
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int PREP_GROUPS = 1024;
+
+struct AmilWs {
+  float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
+  float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
+  int parts, groups, splits, k_per_split, mstk;
+  size_t bytes;
+};
+
+static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated) {
+  AmilWs w{};
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += align_up(nfloat * sizeof(float), 256);
+    return r;
+  };
+  w.parts = gate_parts(D, gated, N);
+  w.groups = pool_groups(N);
+  w.mstk = gated ? 2 * D : D;
+  const int tiles = ((H + 127) / 128) * ((L + 127) / 128) + ((w.mstk + 127) / 128) * ((H + 127) / 128);
+  int splits = 512 / tiles;
+  const int64_t max_splits = (N + 127) / 128;
+  if (splits > max_splits) splits = (int)max_splits;
+  if (splits < 1) splits = 1;
+  w.splits = splits;
+  int64_t kps = (N + splits - 1) / splits;
+  w.k_per_split = (int)((kps + KC - 1) / KC * KC);
+  if (w.k_per_split < KC) w.k_per_split = KC;
+  w.h = take((size_t)N * H);
+  w.a = take((size_t)N * D);
+  w.b = take(gated ? (size_t)N * D : 0);
+  w.s_part = take((size_t)w.parts * N);
+  w.partials = take((size_t)w.groups * (2 + H));
+  w.stats = take(4);
+  w.p = take((size_t)N);
+  w.ds = take((size_t)N);
+  w.dbc_part = take(PREP_GROUPS);
+  w.du = take((size_t)N * H);
+  w.slab_w1 = take((size_t)splits * H * L);
+  w.slab_wab = take((size_t)splits * w.mstk * H);
+  w.cs_b1 = take((size_t)splits * H);
+  w.cs_bab = take((size_t)splits * w.mstk);
+  w.cs_wc = take((size_t)splits * D);
+  w.bytes = off;
+  return w;
+}
+
+static int check_desc(const mmf_amil_desc* d) {
+  if (!d || !d->W1 || !d->b1 || !d->Wa || !d->ba || !d->Wc || !d->bc) return MMF_ERR_ARG;
+  if (d->gated && (!d->Wb || !d->bb)) return MMF_ERR_ARG;
+  if (d->N < 1) return MMF_ERR_SHAPE;
+  if (d->L % KC != 0 || d->H % KC != 0) return MMF_ERR_SHAPE;
+  if (d->H != 256 && d->H != 512 && d->H != 1024) return MMF_ERR_SHAPE;
+  if (d->D % 128 != 0) return MMF_ERR_SHAPE;
+  if (d->N * (int64_t)(d->H > d->D ? d->H : d->D) >= (int64_t)1 << 32) return MMF_ERR_SHAPE;  // 32-bit mask index
+  if (d->p_h < 0.f || d->p_h >= 1.f || d->p_att < 0.f || d->p_att >= 1.f) return MMF_ERR_ARG;
+  return MMF_OK;
+}
+
+}  // namespace mmf
+
+using namespace mmf;
+
+extern "C" {
+
+int mmf_abi_version(void) { return 1; }
+
+const char* mmf_strerror(int code) {
+  switch (code) {
+    case MMF_OK: return "ok";
+    case MMF_ERR_ARG: return "invalid argument (null pointer or bad flag)";
+    case MMF_ERR_SHAPE: return "unsupported shape (need L,H % 32 == 0, H in {256,512,1024}, D % 128 == 0, K % 32 == 0)";
+    case MMF_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+    case MMF_ERR_WORKSPACE: return "workspace too small (see mmf_*_workspace_bytes)";
+    case MMF_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown mmf error";
+  }
+}
+
+size_t mmf_amil_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated) {
+  if (N < 1) N = 1;
+  return carve(nullptr, N, L, H, D, gated).bytes;
+}
+
+int mmf_amil_forward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                     float* M, float* A_raw, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
+  if (!aligned16(x) || !aligned16(workspace) || !aligned16(d->W1) || !aligned16(d->Wa) || (d->gated && !aligned16(d->Wb)))
+    return MMF_ERR_ALIGN;
+  AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  LinearParams lp{};
+  lp.x[0] = x; lp.nseg = 1; lp.kseg = d->L; lp.ldx = d->L;
+  lp.w = d->W1; lp.bias = d->b1; lp.y = w.h;
+  lp.M = d->N; lp.N = d->H; lp.K = d->L;
+  lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0);
+  if (int e = launch_linear(lp, st)) return e;
+
+  GateFwdParams gp{};
+  gp.h = w.h; gp.Wa = d->Wa; gp.ba = d->ba; gp.Wb = d->Wb; gp.bb = d->bb; gp.Wc = d->Wc;
+  gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
+  gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2);
+  if (int e = launch_gate_fwd(gp, st)) return e;
+
+  PoolParams pp{};
+  pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = w.h; pp.N = d->N; pp.H = d->H;
+  pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
+  return launch_pool(pp, st);
+}
+
+int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                      const float* M, const float* A_raw, const float* dM, const float* gA,
+                      const mmf_amil_grads* g, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!x || !workspace || !M || !A_raw || !dM || !g) return MMF_ERR_ARG;
+  if (!g->dW1 || !g->db1 || !g->dWa || !g->dba || !g->dWc || !g->dbc) return MMF_ERR_ARG;
+  if (d->gated && (!g->dWb || !g->dbb)) return MMF_ERR_ARG;
+  if (!aligned16(g->dW1) || !aligned16(g->dWa) || (d->gated && !aligned16(g->dWb)) || (g->dx && !aligned16(g->dx)))
+    return MMF_ERR_ALIGN;
+  AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  BwdPrepParams bp{};
+  bp.h = w.h; bp.A_raw = A_raw; bp.stats = w.stats; bp.dM = dM; bp.M = M; bp.gA = gA;
+  bp.N = d->N; bp.H = d->H; bp.p = w.p; bp.ds = w.ds; bp.dbc_part = w.dbc_part;
+  bp.n_groups = (int)((d->N + 3) / 4 < PREP_GROUPS ? (d->N + 3) / 4 : PREP_GROUPS);
+  if (int e = launch_bwd_prep(bp, st)) return e;
+
+  GateBwdCtx gc{};
+  gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2);
+
+  BwdDhParams dp{};
+  dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
+  dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
+  if (int e = launch_bwd_dh(dp, st)) return e;
+
+  if (g->dx) {   // d(input) = du . W1   (radio: the input is reduce_dim's output)
+    NnParams np{};
+    np.A = w.du; np.lda = d->H; np.B = d->W1; np.ldb = d->L; np.C = g->dx; np.ldc = d->L;
+    np.M = d->N; np.N = d->L; np.K = d->H;
+    if (int e = launch_nn(np, st)) return e;
+  }
+
+  TnParams tp{};
+  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc;
+  TnProblem& q1 = tp.prob[0];   // dW1[H x L] = du^T . x ; db1 = colsum(du)
+  q1.kind = TN_A_PLAIN; q1.A = w.du; q1.lda = d->H; q1.M = d->H;
+  q1.B = x; q1.ldb = d->L; q1.Ncols = d->L;
+  q1.out = w.slab_w1; q1.split_stride = (size_t)d->H * d->L; q1.ldc = d->L;
+  q1.colsum = w.cs_b1; q1.colsum_stride = d->H; q1.colsum2 = nullptr; q1.colsum2_stride = 0;
+  TnProblem& q2 = tp.prob[1];   // dWab[(2)D x H] = dP^T . h ; (dba|dbb) = colsum(dP) ; dWc = colsum(ds.a_d.b_d)
+  q2.kind = TN_A_GATE; q2.A = nullptr; q2.lda = 0; q2.M = w.mstk;
+  q2.B = w.h; q2.ldb = d->H; q2.Ncols = d->H;
+  q2.out = w.slab_wab; q2.split_stride = (size_t)w.mstk * d->H; q2.ldc = d->H;
+  q2.colsum = w.cs_bab; q2.colsum_stride = w.mstk; q2.colsum2 = w.cs_wc; q2.colsum2_stride = d->D;
+  if (int e = launch_tn(tp, st)) return e;
+
+  ReduceParams rp{};
+  int n = 0;
+  auto seg = [&](const float* in, float* out, int len, int nsplit, size_t stride) {
+    rp.seg[n].in = in; rp.seg[n].out = out; rp.seg[n].len = len; rp.seg[n].nsplit = nsplit; rp.seg[n].stride = stride; ++n;
+  };
+  seg(w.slab_w1, g->dW1, d->H * d->L, w.splits, (size_t)d->H * d->L);
+  seg(w.slab_wab, g->dWa, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  if (d->gated) seg(w.slab_wab + (size_t)d->D * d->H, g->dWb, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  seg(w.cs_b1, g->db1, d->H, w.splits, d->H);
+  seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
+  if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
+  seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
+  seg(w.dbc_part, g->dbc, 1, bp.n_groups, 1);
+  rp.nseg = n;
+  return launch_reduce(rp, st);
+}
+
+int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
+                       const float* W, const float* bias, int32_t N, int32_t act,
+                       float drop_p, uint32_t drop_seed, uint32_t drop_site, float* y, void* stream) {
+  if (!x_segs || nseg < 1 || nseg > 4 || !W || !y) return MMF_ERR_ARG;
+  if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  LinearParams lp{};
+  for (int i = 0; i < nseg; ++i) {
+    if (!x_segs[i]) return MMF_ERR_ARG;
+    if (!aligned16(x_segs[i])) return MMF_ERR_ALIGN;
+    lp.x[i] = x_segs[i];
+  }
+  if (!aligned16(W)) return MMF_ERR_ALIGN;
+  lp.nseg = nseg; lp.kseg = kseg; lp.ldx = kseg;
+  lp.w = W; lp.bias = bias; lp.y = y; lp.M = M; lp.N = N; lp.K = nseg * kseg;
+  lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site);
+  return launch_linear(lp, static_cast<hipStream_t>(stream));
+}
+
+static int linear_bwd_splits(int64_t M, int N, int K) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int splits = 512 / tiles;
+  const int64_t max_splits = (M + 127) / 128;
+  if (splits > max_splits) splits = (int)max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+size_t mmf_linear_backward_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  const int s = linear_bwd_splits(M, N, K);
+  if (s == 1) return 256;
+  return align_up((size_t)s * N * K * 4, 256) + align_up((size_t)s * N * 4, 256);
+}
+
+int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
+                        const float* W, int32_t N, float* dW, float* db, float* dx,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !x_segs || nseg < 1 || nseg > 4 || !dW) return MMF_ERR_ARG;
+  if (dx && (nseg != 1 || !W)) return MMF_ERR_ARG;
+  const int K = nseg * kseg;
+  if (N % 4 != 0 || kseg % 4 != 0) return MMF_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int splits = linear_bwd_splits(M, N, K);
+  if (splits > 1 && (!workspace || workspace_bytes < mmf_linear_backward_workspace_bytes(M, N, K))) return MMF_ERR_WORKSPACE;
+  float* slab = splits > 1 ? static_cast<float*>(workspace) : dW;
+  float* cs = splits > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)splits * N * K * 4, 256)) : db;
+
+  TnParams tp{};
+  tp.nprob = nseg; tp.K = M; tp.splits = splits;
+  int64_t kps = (M + splits - 1) / splits;
+  tp.k_per_split = (int)((kps + KC - 1) / KC * KC);
+  for (int i = 0; i < nseg; ++i) {
+    if (!x_segs[i]) return MMF_ERR_ARG;
+    TnProblem& q = tp.prob[i];
+    q.kind = TN_A_PLAIN; q.A = dy; q.lda = N; q.M = N;
+    q.B = x_segs[i]; q.ldb = kseg; q.Ncols = kseg;
+    q.out = slab + (size_t)i * kseg; q.split_stride = (size_t)N * K; q.ldc = K;
+    q.colsum = (i == 0 && db) ? cs : nullptr; q.colsum_stride = N;
+  }
+  if (int e = launch_tn(tp, st)) return e;
+  if (splits > 1) {
+    ReduceParams rp{};
+    rp.seg[0] = ReduceSeg{slab, dW, N * K, splits, (size_t)N * K, 0};
+    rp.nseg = 1;
+    if (db) { rp.seg[1] = ReduceSeg{cs, db, N, splits, (size_t)N, 0}; rp.nseg = 2; }
+    if (int e = launch_reduce(rp, st)) return e;
+  }
+  if (dx) {
+    if (N % KC != 0) return MMF_ERR_SHAPE;
+    NnParams np{};
+    np.A = dy; np.lda = N; np.B = W; np.ldb = K; np.C = dx; np.ldc = K; np.M = M; np.N = K; np.K = N;
+    return launch_nn(np, st);
+  }
+  return MMF_OK;
+}
+
+int mmf_surv_head_forward(const float* feat, const float* Wk, const float* bk, int32_t B, int32_t F, int32_t K,
+                          float* logits, float* hazards, float* S, int64_t* Y_hat, void* stream) {
+  if (!feat || !Wk || !bk || !logits || !hazards || !S || !Y_hat || B < 1 || K < 1) return MMF_ERR_ARG;
+  HeadParams p{feat, Wk, bk, B, F, K, logits, hazards, S, Y_hat};
+  return launch_head_fwd(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_surv_head_backward(const float* g_hazards, const float* g_S, const float* hazards, const float* feat,
+                           const float* Wk, int32_t B, int32_t F, int32_t K,
+                           float* dfeat, float* dWk, float* dbk, void* stream) {
+  if (!hazards || !feat || !Wk || !dfeat || !dWk || !dbk || B < 1 || K < 1) return MMF_ERR_ARG;
+  HeadBwdParams p{g_hazards, g_S, hazards, feat, Wk, B, F, K, dfeat, dWk, dbk};
+  return launch_head_bwd(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_nll_surv(const float* hazards, const float* S, const int64_t* Y, const float* c, int32_t B, int32_t K,
+                 float alpha, float eps, float* loss, float* g_hazards, float* g_S, void* stream) {
+  if (!hazards || !S || !Y || !c || !loss || !g_hazards || !g_S || B < 1 || K < 1) return MMF_ERR_ARG;
+  NllParams p{hazards, S, Y, c, B, K, alpha, eps, loss, g_hazards, g_S};
+  return launch_nll(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_t B,
+                 float* loss, float* d_risks, void* stream) {
+  if (!risks || !times || !c || !loss || !d_risks || B < 1) return MMF_ERR_ARG;
+  CoxParams p{risks, times, c, B, loss, d_risks};
+  return launch_cox(p, static_cast<hipStream_t>(stream));
+}
+
+void mmf_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_prof_on = on != 0;
+}
+
+// Synchronises on the recorded events, writes "name count total_ms\n" lines, clears the records.
+int mmf_profile_dump(char* buf, size_t buf_bytes) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  std::map<std::string, std::pair<int, double>> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& e = agg[r.name];
+      e.first += 1;
+      e.second += ms;
+    }
+    if (r.a) hipEventDestroy(r.a);
+    if (r.b) hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof line, "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (!buf || buf_bytes == 0) return (int)out.size();
+  size_t n = out.size() < buf_bytes - 1 ? out.size() : buf_bytes - 1;
+  memcpy(buf, out.data(), n);
+  buf[n] = 0;
+  return (int)n;
+}
+
+int mmf_dropout_keep_host(uint32_t seed, uint32_t site, uint32_t index, float p) {
+  return keep(drop_key(seed, site), index, drop_threshold(p)) ? 1 : 0;
+}
+
+}  // extern "C"

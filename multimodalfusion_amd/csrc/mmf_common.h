@@ -1,0 +1,67 @@
+// Common device/host helpers for the MI355X (gfx950) attention-MIL kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error codes returned through the C ABI (include/mmf_amil.h) -------------------
+enum : int {
+  MMF_OK = 0,
+  MMF_ERR_ARG = -1,       // null pointer / bad enum
+  MMF_ERR_SHAPE = -2,     // unsupported dimension (see mmf_strerror)
+  MMF_ERR_ALIGN = -3,     // pointer or leading dimension not 16-byte aligned
+  MMF_ERR_WORKSPACE = -4, // workspace too small
+  MMF_ERR_LAUNCH = -5,    // hipGetLastError() != hipSuccess after a launch
+};
+
+// ---- dropout keep-hash ---------------------------------------------------------------
+// keep(key, idx): 32-bit counter hash (murmur3 finaliser); idx = row*cols+col (uint32 wrap).
+// The oracle restates it bit-exactly (oracle/inputs.py: keep_mask) so train-mode parity is
+// checked with the very mask the device uses.  The mask is regenerated in backward, never
+// stored.  Replaces nn.Dropout(0.25) of models/model_attention_mil_path.py:21 and
+// models/model_modules.py:97-99 in the reference.
+__host__ __device__ inline uint32_t drop_key(uint32_t seed, uint32_t site) {
+  return seed + 0x632BE5ABu * (site + 1u);
+}
+__host__ __device__ inline uint32_t hash_u32(uint32_t key, uint32_t idx) {
+  uint32_t h = idx * 0x9E3779B1u + key;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__host__ __device__ inline uint32_t drop_threshold(float p) { return (uint32_t)(p * 16777216.0f); }
+__host__ __device__ inline bool keep(uint32_t key, uint32_t idx, uint32_t thr) {
+  return (hash_u32(key, idx) >> 8) >= thr;
+}
+
+// ---- fast transcendental forms (abs error ~2e-7, far inside the 1e-4 parity bar) -----
+__device__ inline float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ inline float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 32 lanes that share (lane >> 5)
+__device__ inline float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ inline float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+}  // namespace mmf

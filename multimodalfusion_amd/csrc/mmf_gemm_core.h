@@ -1,0 +1,251 @@
+// LDS-tiled exact-fp32 MFMA GEMM core for gfx950 (v_mfma_f32_32x32x2_f32), shared by every
+// contraction on the attention-MIL path:
+//
+//   NT  C[m][n] = sum_k A[m][k] * B[n][k]     both operands k-contiguous   (x.W1^T, h.Wab^T)
+//   NN  C[m][n] = sum_k A[m][k] * B[k][n]     A k-contiguous, B n-contiguous (dP.Wab)
+//   TN  C[m][n] = sum_k A[k][m] * B[k][n]     both operands k-major          (du^T.x split-K)
+//
+// Design (wave64, one workgroup = WM x WN waves, each wave owns MB x NB accumulator blocks of
+// 32x32):  operands are streamed through LDS in k-chunks of KC = 32, double-buffered, one
+// barrier per chunk; the global loads of chunk t+1 are issued before the MFMAs of chunk t and
+// written to LDS after them (register staging, issue-early / write-late).
+//
+// An operand's LDS image keeps the layout it has in HBM, so staging is a straight 16-byte
+// copy (coalesced global_load_dwordx4 -> ds_write_b128):
+//   k-contiguous  : [rows][KC+4]  fragment = ONE ds_read_b128 per 4 MFMAs; the +4 pad makes
+//                   the 16-lane read groups hit 16 distinct 16-B slots (stride 9 slots, odd).
+//   m-contiguous  : [KC][rows]    fragment = 4 ds_read_b32, lanes 0..31 on consecutive banks.
+// The 32x32x2 MFMA takes A[i = lane&31][k = lane>>5] / B[k = lane>>5][j = lane&31].  Inside a
+// group of 8 k-values lane-half hh holds k = 8q + 4hh + j (j = 0..3), i.e. MFMA j contracts
+// k in {8q+j, 8q+4+j}; A and B use the same mapping, and a sum does not care about k order.
+//
+// C/D layout (guide: cdna_hip_programming.md section 3): col = lane & 31,
+// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#pragma once
+#include "mmf_common.h"
+
+namespace mmf {
+
+constexpr int KC = 32;         // k-chunk staged per pipeline step
+constexpr int KSTR = KC + 4;   // padded LDS row stride (floats) of a k-contiguous image
+
+template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr bool A_KCONTIG = A_KCONTIG_, B_KCONTIG = B_KCONTIG_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
+  static constexpr int A_STRIDE = A_KCONTIG ? KSTR : BM;
+  static constexpr int B_STRIDE = B_KCONTIG ? KSTR : BN;
+  static constexpr int A_FLOATS = A_KCONTIG ? BM * KSTR : KC * BM;
+  static constexpr int B_FLOATS = B_KCONTIG ? BN * KSTR : KC * BN;
+  static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+  static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be a multiple of 32x32");
+};
+
+// thread -> (row, 16-byte column) maps of one staged chunk --------------------------------
+template <int ROWS, int NT>
+struct KMap {   // k-contiguous image [ROWS][KC]: 8 float4 per row
+  static constexpr int NV = (ROWS * (KC / 4) + NT - 1) / NT;
+  static constexpr bool EXACT = (ROWS * (KC / 4)) % NT == 0;
+  __device__ static inline int idx(int tid, int i) { return tid + i * NT; }
+  __device__ static inline bool valid(int tid, int i) { return EXACT || idx(tid, i) < ROWS * (KC / 4); }
+  __device__ static inline int row(int tid, int i) { return idx(tid, i) >> 3; }
+  __device__ static inline int c4(int tid, int i) { return idx(tid, i) & 7; }
+  __device__ static inline int lds(int tid, int i) { return row(tid, i) * KSTR + 4 * c4(tid, i); }
+};
+template <int ROWS, int NT>
+struct MMap {   // m-contiguous image [KC][ROWS]: ROWS/4 float4 per k-row
+  static constexpr int VPR = ROWS / 4;
+  static constexpr int NV = (KC * VPR + NT - 1) / NT;
+  static constexpr bool EXACT = (KC * VPR) % NT == 0;
+  __device__ static inline int idx(int tid, int i) { return tid + i * NT; }
+  __device__ static inline bool valid(int tid, int i) { return EXACT || idx(tid, i) < KC * VPR; }
+  __device__ static inline int krow(int tid, int i) { return idx(tid, i) / VPR; }
+  __device__ static inline int c4(int tid, int i) { return idx(tid, i) % VPR; }
+  __device__ static inline int lds(int tid, int i) { return krow(tid, i) * ROWS + 4 * c4(tid, i); }
+};
+
+// ---- generic loaders ----------------------------------------------------------------------
+// k-contiguous source S[row][k] (leading dimension ld); rows >= nrows read as zero.  The k range
+// may be a concatenation of `nseg` equal segments held in separate buffers (radio: the four
+// modality bags are never concatenated in memory, models/model_attention_mil_radio.py:80-82).
+template <int ROWS, int NT>
+struct LoadK {
+  using Map = KMap<ROWS, NT>;
+  const float *s0, *s1, *s2, *s3;
+  int kseg, ld, row0, nrows, tid;
+  float4 r[Map::NV];
+  __device__ inline void init(const float* p0, int ld_, int row0_, int nrows_) {
+    s0 = p0; s1 = s2 = s3 = nullptr; kseg = 1 << 30;
+    ld = ld_; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+  }
+  __device__ inline void init_segments(const float* const* p, int nseg, int kseg_, int ld_, int row0_, int nrows_) {
+    s0 = p[0]; s1 = nseg > 1 ? p[1] : nullptr; s2 = nseg > 2 ? p[2] : nullptr; s3 = nseg > 3 ? p[3] : nullptr;
+    kseg = kseg_; ld = ld_; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+  }
+  __device__ inline void load(int kt) {
+    int k0 = kt * KC;
+    int sidx = k0 / kseg;
+    const float* base = (sidx == 0 ? s0 : sidx == 1 ? s1 : sidx == 2 ? s2 : s3) + (k0 - sidx * kseg);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      // unconditional load from a clamped (always valid) address, then select: a predicated load
+      // would compile to an exec-masked branch + vmcnt(0) per element
+      int rr = row0 + Map::row(tid, i);
+      int rc = rr < nrows ? rr : nrows - 1;
+      r[i] = ld4(base + (size_t)rc * ld + 4 * Map::c4(tid, i));
+    }
+  }
+  // the zero-select sits HERE (after the MFMAs of the previous chunk), not in load(): a select in
+  // load() makes the compiler wait for the loads before the MFMA block they are meant to overlap
+  __device__ inline void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      bool ok = row0 + Map::row(tid, i) < nrows;
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), ok ? r[i] : zero4());
+    }
+  }
+};
+
+// m-contiguous source S[k][m]; k rows outside [0, kmax) and columns >= ncols read as zero.
+template <int ROWS, int NT>
+struct LoadM {
+  using Map = MMap<ROWS, NT>;
+  const float* src;
+  int ld, col0, ncols, kbase, kmax, tid, kt_loaded;
+  float4 r[Map::NV];
+  __device__ inline void init(const float* s, int ld_, int col0_, int ncols_, int kbase_, int kmax_) {
+    src = s; ld = ld_; col0 = col0_; ncols = ncols_; kbase = kbase_; kmax = kmax_; tid = threadIdx.x;
+    kt_loaded = 0;
+  }
+  __device__ inline void load(int kt) {
+    kt_loaded = kt;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int k = kbase + kt * KC + Map::krow(tid, i);
+      int c = col0 + 4 * Map::c4(tid, i);
+      int kc = k < kmax ? k : kmax - 1;
+      int cc = c < ncols ? c : ncols - 4;
+      r[i] = ld4(src + (size_t)kc * ld + cc);
+    }
+  }
+  __device__ inline void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int k = kbase + kt_loaded * KC + Map::krow(tid, i);
+      int c = col0 + 4 * Map::c4(tid, i);
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), (k < kmax && c < ncols) ? r[i] : zero4());
+    }
+  }
+};
+
+// ---- MFMA over one staged chunk ---------------------------------------------------------------
+template <class T>
+__device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                     f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+  const int arow = wm * T::MB * 32 + r;
+  const int brow = wn * T::NB * 32 + r;
+#pragma unroll
+  for (int q = 0; q < KC / 8; ++q) {
+    float av[T::MB][4], bv[T::NB][4];
+#pragma unroll
+    for (int mb = 0; mb < T::MB; ++mb) {
+      if constexpr (T::A_KCONTIG) {
+        float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * q + 4 * hh);
+        av[mb][0] = t.x; av[mb][1] = t.y; av[mb][2] = t.z; av[mb][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[mb][j] = As[(8 * q + 4 * hh + j) * T::BM + arow + mb * 32];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) {
+      if constexpr (T::B_KCONTIG) {
+        float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * q + 4 * hh);
+        bv[nb][0] = t.x; bv[nb][1] = t.y; bv[nb][2] = t.z; bv[nb][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[nb][j] = Bs[(8 * q + 4 * hh + j) * T::BN + brow + nb * 32];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < T::NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][j], bv[nb][j], acc[mb][nb], 0, 0, 0);
+  }
+}
+
+// ---- double-buffered main loop ---------------------------------------------------------------
+// Loader concept: load(kt) issues the global loads of chunk kt into the loader's registers,
+// store(lds) writes them (possibly transformed) into the operand's LDS image.
+template <class T, class LA, class LB>
+__device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  if (nk <= 0) return;
+  la.load(0);
+  lb.load(0);
+  la.store(lds);
+  lb.store(lds + T::A_FLOATS);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    float* cur = lds + (kt & 1) * T::STAGE_FLOATS;
+    float* nxt = lds + ((kt + 1) & 1) * T::STAGE_FLOATS;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      la.load(kt + 1);
+      lb.load(kt + 1);
+    }
+    compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane);
+    if (more) {
+      la.store(nxt);
+      lb.store(nxt + T::A_FLOATS);
+    }
+    __syncthreads();
+  }
+}
+
+// visit every accumulator element this lane owns: f(row_in_tile, col_in_tile, value)
+template <class T, class F>
+__device__ inline void for_each_c(f32x16 (&acc)[T::MB][T::NB], F&& f) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        int col = (wn * T::NB + nb) * 32 + r;
+        f(row, col, acc[mb][nb][i]);
+      }
+}
+
+// XCD-aware block -> (m-tile, n-tile) map.  Blocks b and b+8 land on the same XCD (round-robin
+// dispatch; speed only, never correctness), so the n-tiles of one m-tile are put 8 apart: they
+// share the streamed A rows through that XCD's L2.  Returns false for the padding blocks of a
+// grid rounded up to a multiple of 8*ntn.
+__device__ inline bool tile_of_block(int b, int mt_count, int ntn, int& mt, int& nt) {
+  int group = b / (8 * ntn);
+  int within = b - group * 8 * ntn;
+  nt = within / 8;
+  mt = group * 8 + (within & 7);
+  return mt < mt_count;
+}
+inline int grid_for_tiles(int mt_count, int ntn) { return ((mt_count + 7) / 8) * 8 * ntn; }
+
+}  // namespace mmf

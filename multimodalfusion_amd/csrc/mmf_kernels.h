@@ -1,0 +1,140 @@
+// Internal parameter blocks and launcher prototypes shared by the .hip translation units.
+// (The public C ABI is include/mmf_amil.h; nothing here is exported.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmf {
+
+enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_SELU = 4 };
+
+struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K]^T + bias))
+  const float* x[4];
+  int nseg, kseg, ldx;
+  const float* w;
+  const float* bias;
+  float* y;
+  int64_t M;
+  int N, K;
+  int act;
+  float drop_p;
+  uint32_t drop_key;
+  int mt_count, nt_count;
+};
+
+struct GateFwdParams {
+  const float* h;          // [N x H] (post ReLU/dropout)
+  const float *Wa, *ba, *Wb, *bb, *Wc;
+  float *a, *b;            // [N x D] un-dropped activations, saved for backward
+  float* s_part;           // [nt_count x N]
+  int64_t N;
+  int H, D, gated;
+  float drop_p;            // dropout on a / b (model_modules.py:97-99), 0 = off
+  uint32_t key_a, key_b;
+  int mt_count, nt_count;
+};
+
+struct PoolParams {
+  const float* s_part;
+  int n_parts;
+  const float* bc;         // device scalar (attention_c.bias)
+  const float* h;
+  int64_t N;
+  int H;
+  float* A_raw;            // [N]
+  float* partials;         // [n_groups x (2 + H)]
+  float* M;                // [H]
+  float* stats;            // {max, denom}
+  int n_groups, rows_per_group;
+};
+
+struct BwdPrepParams {     // ds_i = p_i (dM.h_i - dM.M) + gA_i
+  const float* h;
+  const float* A_raw;
+  const float* stats;
+  const float* dM;         // [H]
+  const float* M;          // [H]
+  const float* gA;         // [N] or null
+  int64_t N;
+  int H;
+  float* p;                // [N]
+  float* ds;               // [N]
+  float* dbc_part;         // [n_groups]
+  int n_groups;
+};
+
+struct GateBwdCtx {        // what the on-the-fly dP operand needs
+  const float *a, *b, *ds, *Wc;
+  int D, gated;
+  float drop_p;
+  uint32_t key_a, key_b;
+};
+
+struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
+  GateBwdCtx g;
+  const float *Wa, *Wb;    // [D x H]
+  const float* p;          // [N]
+  const float* dM;         // [H]
+  const float* h;          // [N x H]
+  float* du;               // [N x H]
+  int64_t N;
+  int H;
+  float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
+  int mt_count, nt_count;
+};
+
+enum : int { TN_A_PLAIN = 0, TN_A_GATE = 1 };
+
+struct TnProblem {         // C[M x Ncols] (+)= A^T . B over a slice of the K (instance) range
+  int kind;
+  const float* A; int lda; int M;          // TN_A_PLAIN: A[k][m]; TN_A_GATE: M = 2D (gated) or D
+  const float* B; int ldb; int Ncols;      // B[k][n]
+  float* out; size_t split_stride; int ldc;  // slab s at out + s*split_stride
+  float* colsum; size_t colsum_stride;       // per split: column sums of A (bias grads), length M; null = skip
+  float* colsum2; size_t colsum2_stride;     // TN_A_GATE only: dWc partials, length D
+  int tiles_m, tiles_n, block_begin;
+};
+
+struct TnParams {
+  TnProblem prob[6];
+  int nprob;
+  int64_t K;               // number of instances (rows of A and B)
+  int splits, k_per_split; // k_per_split is a multiple of KC
+  GateBwdCtx g;
+};
+
+struct NnParams {          // C[M x N] = A[M x K] . B[K x N]   (plain; radio: dh0 = du.W1)
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int64_t M;
+  int N, K;
+  int mt_count, nt_count;
+};
+
+struct ReduceSeg { const float* in; float* out; int len; int nsplit; size_t stride; int block_begin; };
+struct ReduceParams { ReduceSeg seg[12]; int nseg; };
+
+int launch_linear(LinearParams p, hipStream_t st);
+int gate_parts(int D, int gated, int64_t N);
+int launch_gate_fwd(GateFwdParams p, hipStream_t st);
+int pool_groups(int64_t N);
+int launch_pool(PoolParams p, hipStream_t st);
+int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
+int launch_bwd_dh(BwdDhParams p, hipStream_t st);
+int launch_tn(TnParams p, hipStream_t st);
+int launch_nn(NnParams p, hipStream_t st);
+int launch_reduce(ReduceParams p, hipStream_t st);
+int set_dyn_lds(const void* kern, int bytes);
+
+// Optional per-kernel timing with HIP events on the launch stream (off by default; enabled by
+// mmf_profile_enable() for bench.py's roofline leg).  No cost when disabled.
+void prof_begin(const char* name, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+  hipStream_t st;
+  ProfScope(const char* name, hipStream_t s) : st(s) { prof_begin(name, s); }
+  ~ProfScope() { prof_end(st); }
+};
+
+}  // namespace mmf

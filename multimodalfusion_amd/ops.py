@@ -1,0 +1,235 @@
+"""torch.autograd Functions over the C ABI (include/mmf_amil.h).
+
+PyTorch is used for device memory, streams and the autograd graph only; every arithmetic
+step of the path runs in the HIP kernels of libmmf_amil.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AmilDesc, AmilGrads, check, lib, ptr, stream_ptr
+
+ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}
+
+_drop_calls = 0
+
+
+def next_dropout_seed() -> int:
+    """Per-call dropout seed: deterministic given torch.manual_seed(), no device sync."""
+    global _drop_calls
+    _drop_calls += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _drop_calls * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise _lib.MmfError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+class AmilPoolFn(torch.autograd.Function):
+    """(x, attention-stack params) -> (M [1 x H], A_raw [1 x N]).
+
+    Mirrors `A, h = attention_net(x); A = A.T; A_raw = A; M = softmax(A) @ h`
+    (models/model_attention_mil_path.py:52-56 in the reference).
+    """
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed):
+        x = _f32c(x)
+        W1, b1, Wa, ba, Wc, bc = map(_f32c, (W1, b1, Wa, ba, Wc, bc))
+        Wb, bb = _f32c(Wb), _f32c(bb)
+        if x.dim() != 2:
+            raise _lib.MmfError(f"bag must be [N x L], got {tuple(x.shape)}")
+        N, L = x.shape
+        H, D = W1.shape[0], Wa.shape[0]
+        if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D:
+            raise _lib.MmfError("attention stack shapes do not match the bag")
+        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF)
+        l = lib()
+        nbytes = l.mmf_amil_workspace_bytes(N, L, H, D, d.gated)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        M = torch.empty((1, H), dtype=torch.float32, device=x.device)
+        A_raw = torch.empty((1, N), dtype=torch.float32, device=x.device)
+        check(l.mmf_amil_forward(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), stream_ptr()),
+              "mmf_amil_forward")
+        ctx.desc_args = (N, L, H, D, bool(gated), float(p_h), float(p_att), int(seed) & 0xFFFFFFFF)
+        ctx.ws = ws
+        ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw)
+        return M, A_raw
+
+    @staticmethod
+    def backward(ctx, gM, gA):
+        x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw = ctx.saved_tensors
+        N, L, H, D, gated, p_h, p_att, seed = ctx.desc_args
+        dev = x.device
+        gM = torch.zeros((1, H), dtype=torch.float32, device=dev) if gM is None else _f32c(gM)
+        gA = _f32c(gA) if gA is not None else None
+        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                     Wc=ptr(Wc), bc=ptr(bc), p_h=p_h, p_att=p_att, seed=seed)
+        new = lambda ref: torch.empty_like(ref)
+        dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
+        dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g = AmilGrads(dW1=ptr(dW1), db1=ptr(db1), dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb), dbb=ptr(dbb),
+                      dWc=ptr(dWc), dbc=ptr(dbc), dx=ptr(dx))
+        ws = ctx.ws
+        check(lib().mmf_amil_backward(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(M), ptr(A_raw),
+                                      ptr(gM), ptr(gA), C.byref(g), stream_ptr()), "mmf_amil_backward")
+        return dx, dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, None, None, None, None
+
+
+def amil_pool(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h=0.0, p_att=0.0, seed=0):
+    return AmilPoolFn.apply(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
+
+
+class LinearCatFn(torch.autograd.Function):
+    """y = cat(xs, dim=1) @ W.T + b without materialising the concatenation
+    (models/model_attention_mil_radio.py:80-82)."""
+
+    @staticmethod
+    def forward(ctx, W, b, *xs):
+        xs = [_f32c(x) for x in xs]
+        W, b = _f32c(W), _f32c(b)
+        M, kseg = xs[0].shape
+        for x in xs:
+            if tuple(x.shape) != (M, kseg):
+                raise _lib.MmfError("all concatenated segments must have the same [M x k] shape")
+        nseg = len(xs)
+        N = W.shape[0]
+        if W.shape[1] != nseg * kseg:
+            raise _lib.MmfError("weight does not match the concatenated width")
+        y = torch.empty((M, N), dtype=torch.float32, device=W.device)
+        segs = (C.c_void_p * nseg)(*[ptr(x) for x in xs])
+        check(lib().mmf_linear_forward(segs, nseg, kseg, M, ptr(W), ptr(b), N, ACT["none"], 0.0, 0, 0,
+                                       ptr(y), stream_ptr()), "mmf_linear_forward")
+        ctx.save_for_backward(W, *xs)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        W, *xs = ctx.saved_tensors
+        gy = _f32c(gy)
+        M, kseg = xs[0].shape
+        nseg = len(xs)
+        N, K = W.shape
+        l = lib()
+        dW = torch.empty_like(W)
+        db = torch.empty((N,), dtype=torch.float32, device=W.device) if ctx.has_bias else None
+        need_dx = any(ctx.needs_input_grad[2:])
+        if need_dx and nseg != 1:
+            raise _lib.MmfError("input gradient of a concatenated linear is not provided (bags are leaves)")
+        dx = torch.empty_like(xs[0]) if need_dx else None
+        nbytes = l.mmf_linear_backward_workspace_bytes(M, N, K)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+        segs = (C.c_void_p * nseg)(*[ptr(x) for x in xs])
+        check(l.mmf_linear_backward(ptr(gy), segs, nseg, kseg, M, ptr(W), N, ptr(dW), ptr(db), ptr(dx),
+                                    ptr(ws), nbytes, stream_ptr()), "mmf_linear_backward")
+        return (dW, db) + ((dx,) if nseg == 1 else (None,) * nseg)
+
+
+def linear_cat(xs, W, b):
+    return LinearCatFn.apply(W, b, *xs)
+
+
+class SurvHeadFn(torch.autograd.Function):
+    """feat [B x F] -> hazards, S [B x K], Y_hat [B x 1] (models/model_attention_mil_path.py:58-61)."""
+
+    @staticmethod
+    def forward(ctx, feat, Wk, bk):
+        feat, Wk, bk = _f32c(feat), _f32c(Wk), _f32c(bk)
+        B, F = feat.shape
+        K = Wk.shape[0]
+        dev = feat.device
+        logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+        hazards = torch.empty_like(logits)
+        S = torch.empty_like(logits)
+        Y_hat = torch.empty((B, 1), dtype=torch.int64, device=dev)
+        check(lib().mmf_surv_head_forward(ptr(feat), ptr(Wk), ptr(bk), B, F, K, ptr(logits), ptr(hazards),
+                                          ptr(S), ptr(Y_hat), stream_ptr()), "mmf_surv_head_forward")
+        ctx.save_for_backward(feat, Wk, hazards)
+        ctx.mark_non_differentiable(Y_hat)
+        return hazards, S, Y_hat
+
+    @staticmethod
+    def backward(ctx, gH, gS, _gY):
+        feat, Wk, hazards = ctx.saved_tensors
+        B, F = feat.shape
+        K = Wk.shape[0]
+        gH = _f32c(gH) if gH is not None else None
+        gS = _f32c(gS) if gS is not None else None
+        dfeat = torch.empty_like(feat)
+        dWk = torch.empty_like(Wk)
+        dbk = torch.empty((K,), dtype=torch.float32, device=feat.device)
+        check(lib().mmf_surv_head_backward(ptr(gH), ptr(gS), ptr(hazards), ptr(feat), ptr(Wk), B, F, K,
+                                           ptr(dfeat), ptr(dWk), ptr(dbk), stream_ptr()), "mmf_surv_head_backward")
+        return dfeat, dWk, dbk
+
+
+def surv_head(feat, Wk, bk):
+    return SurvHeadFn.apply(feat, Wk, bk)
+
+
+class NllSurvFn(torch.autograd.Function):
+    """utils/loss_utils.py:22-39; loss and both input gradients come out of one launch."""
+
+    @staticmethod
+    def forward(ctx, hazards, S, Y, c, alpha, eps):
+        hazards, S = _f32c(hazards), _f32c(S)
+        B, K = hazards.shape
+        Y = Y.reshape(B).to(torch.int64).contiguous()
+        c = c.reshape(B).to(torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=hazards.device)
+        gH = torch.empty_like(hazards)
+        gS = torch.empty_like(S)
+        check(lib().mmf_nll_surv(ptr(hazards), ptr(S), ptr(Y), ptr(c), B, K, float(alpha), float(eps),
+                                 ptr(loss), ptr(gH), ptr(gS), stream_ptr()), "mmf_nll_surv")
+        ctx.save_for_backward(gH, gS)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        gH, gS = ctx.saved_tensors
+        return gH * g, gS * g, None, None, None, None
+
+
+def nll_surv(hazards, S, Y, c, alpha=0.4, eps=1e-7):
+    return NllSurvFn.apply(hazards, S, Y, c, alpha, eps)
+
+
+class CoxSurvFn(torch.autograd.Function):
+    """utils/loss_utils.py:124-139."""
+
+    @staticmethod
+    def forward(ctx, risks, times, c):
+        shape = risks.shape
+        r = _f32c(risks.reshape(-1))
+        B = r.numel()
+        t = times.reshape(B).to(device=r.device, dtype=torch.float64).contiguous()
+        cc = c.reshape(B).to(device=r.device, dtype=torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=r.device)
+        dr = torch.empty_like(r)
+        check(lib().mmf_cox_surv(ptr(r), ptr(t), ptr(cc), B, ptr(loss), ptr(dr), stream_ptr()), "mmf_cox_surv")
+        ctx.save_for_backward(dr)
+        ctx.shape = shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dr,) = ctx.saved_tensors
+        return (dr * g).reshape(ctx.shape), None, None
+
+
+def cox_surv(risks, times, c):
+    return CoxSurvFn.apply(risks, times, c)

@@ -1,0 +1,218 @@
+"""GPU parity: the HIP path (through the drop-in modules -> C ABI) against the golden fixtures
+made from the reference and against the live fp64 oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): attention scores / hazards within 1e-4 abs, loss within 1e-5;
+gradients 1e-5 abs + 1e-4 rel of the tensor's max.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_summary
+from oracle import cases
+from oracle import inputs as gen
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a)).to(dtype).to(DEV)
+
+
+def _load(model, sd_np):
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd_np.items()}, strict=True)
+    return model.to(DEV)
+
+
+def _grads(model):
+    return {k: (p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32))
+            for k, p in model.named_parameters()}
+
+
+def run_path_hip(m, monkeypatch=None):
+    from multimodalfusion_amd import ops
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    sd, x, masks = cases.path_inputs(m)
+    model = _load(MIL_Attention_fc_surv_path(gate_path=m["gated"], model_size_wsi=m["size"],
+                                             dropout=m["dropout"], n_classes=m["K"]), sd)
+    if m["train"]:
+        model.train()
+        monkeypatch.setattr(ops, "next_dropout_seed", lambda: m["mask_seed"])
+    else:
+        model.eval()
+    xt = _t(x)
+    hz, S, Yh, A_raw = model(path_features=xt)
+    loss = NLLSurvLoss(alpha=m["alpha"])(hazards=hz, S=S, Y=torch.tensor([m["y"]], device=DEV),
+                                         c=torch.tensor([float(m["c"])], device=DEV))
+    loss.backward()
+    M = None
+    if not m["train"]:
+        with torch.no_grad():
+            M = model(path_features=xt, return_features=True).cpu().numpy()
+    torch.cuda.synchronize()
+    return dict(hazards=hz.detach().cpu().numpy(), S=S.detach().cpu().numpy(), Y_hat=Yh.cpu().numpy(),
+                A_raw=A_raw.detach().cpu().numpy(), loss=float(loss), M=M, grads=_grads(model))
+
+
+def compare(res, ref, tag=""):
+    """res: HIP fp32 results; ref: fp64 oracle results (same dict layout)."""
+    assert abs(res["loss"] - float(ref["loss"])) <= 1e-5, (tag, res["loss"], float(ref["loss"]))
+    np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=1e-4, err_msg=tag)
+    np.testing.assert_allclose(res["S"], ref["S"], rtol=0, atol=1e-4, err_msg=tag)
+    if isinstance(ref["A_raw"], dict):
+        for k in ref["A_raw"]:
+            np.testing.assert_allclose(res["A_raw"][k], ref["A_raw"][k], rtol=0, atol=1e-4, err_msg=tag + k)
+    else:
+        np.testing.assert_allclose(res["A_raw"], ref["A_raw"], rtol=0, atol=1e-4, err_msg=tag)
+    if res.get("M") is not None and ref.get("M") is not None:
+        np.testing.assert_allclose(res["M"], ref["M"], rtol=0, atol=1e-4, err_msg=tag)
+    # argmax may legitimately differ only on a near-tie
+    for k, g in ref["grads"].items():
+        got = res["grads"][k]
+        tol = 1e-5 + 1e-4 * max(float(np.abs(g).max()), 1e-30)
+        err = float(np.abs(got - g).max())
+        assert err <= tol, f"{tag} grad {k}: max abs err {err:.3e} > {tol:.3e}"
+
+
+def test_path_golden_cases(golden, monkeypatch):
+    """Every path fixture: HIP vs (a) the committed reference outputs, (b) the live oracle."""
+    g = golden("path")
+    for name, m in g.meta.items():
+        if m["N"] > 2000:
+            continue
+        res = run_path_hip(m, monkeypatch)
+        ref = cases.run_path(m)
+        compare(res, ref, name)
+        tag = name + "/f64"
+        assert abs(res["loss"] - float(g[tag + "/loss"])) <= 1e-5
+        np.testing.assert_allclose(res["hazards"], g[tag + "/hazards"], rtol=0, atol=1e-4)
+        assert np.array_equal(res["Y_hat"], g[tag + "/Y_hat"])
+        check_summary(g, tag + "/A_raw", res["A_raw"], rtol=0, atol=1e-4)
+        for k, gr in res["grads"].items():
+            check_summary(g, f"{tag}/grad/{k}", gr, rtol=1e-4, atol=1e-5)
+
+
+def test_path_golden_10k(golden, monkeypatch):
+    g = golden("path")
+    name = "g_small_k4_n10000"
+    m = g.meta[name]
+    res = run_path_hip(m, monkeypatch)
+    tag = name + "/f64"
+    assert abs(res["loss"] - float(g[tag + "/loss"])) <= 1e-5
+    np.testing.assert_allclose(res["hazards"], g[tag + "/hazards"], rtol=0, atol=1e-4)
+    check_summary(g, tag + "/A_raw", res["A_raw"], rtol=0, atol=1e-4)
+    a = res["A_raw"].reshape(-1)
+    assert abs(float(np.log(np.exp(a - a.max()).sum()) + a.max()) - float(g[tag + "/A_raw/logsumexp"])) < 1e-4
+    for k, gr in res["grads"].items():
+        check_summary(g, f"{tag}/grad/{k}", gr, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N", [1, 2, 31, 63, 64, 65, 127, 129, 255, 1023, 4097])
+@pytest.mark.parametrize("gated", [True, False])
+def test_path_ragged_sizes(N, gated):
+    """Tile-edge bag sizes (N not a multiple of any tile, N = 1) against the live oracle."""
+    m = dict(N=N, gated=gated, size="small", K=4, dropout=False, y=N % 4, c=N % 2, alpha=0.15, bias_std=0.05,
+             train=False, seed=4000 + N, x_seed=5000 + N, mask_seed=0)
+    compare(run_path_hip(m), cases.run_path(m), f"N={N} gated={gated}")
+
+
+def test_path_big_model_train_masks(monkeypatch):
+    """big (1024/512/384) model in train mode with all three dropout sites: the oracle rebuilds the
+    device masks from the same integer hash, so train mode is compared exactly, not distributionally."""
+    for gated in (True, False):
+        m = dict(N=700, gated=gated, size="big", K=8, dropout=True, y=5, c=0, alpha=0.0, bias_std=0.05,
+                 train=True, seed=4100, x_seed=5100, mask_seed=777)
+        compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"big train gated={gated}")
+
+
+def test_dropout_mask_matches_host_hash():
+    """Device mask == oracle mask == C-ABI host restatement (bit-exact integer hash)."""
+    from multimodalfusion_amd import _lib
+    l = _lib.lib()
+    keep = gen.keep_mask(123, 2, 10, 256, 0.25)
+    for (r, c) in [(0, 0), (3, 17), (9, 255), (5, 128)]:
+        assert bool(l.mmf_dropout_keep_host(123, 2, r * 256 + c, 0.25)) == bool(keep[r, c])
+
+
+def test_permutation_and_shift_invariance():
+    """Property tests at a size the oracle is not needed for: permuting instances permutes A_raw and
+    leaves (hazards, grads) unchanged; shifting attention_c.bias shifts A_raw only, and its gradient is 0."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    torch.manual_seed(0)
+    model = MIL_Attention_fc_surv_path(gate_path=True, n_classes=4).to(DEV).eval()
+    N = 20000
+    x = torch.randn(N, 1024, device=DEV)
+    perm = torch.randperm(N, device=DEV)
+
+    def step(xx):
+        model.zero_grad()
+        hz, S, Yh, A = model(path_features=xx)
+        loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.], device=DEV))
+        loss.backward()
+        return hz.detach(), A.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    hz1, A1, g1 = step(x)
+    hz2, A2, g2 = step(x[perm])
+    assert torch.allclose(A1[0, perm], A2[0], atol=1e-5)
+    assert torch.allclose(hz1, hz2, atol=1e-5)
+    for k in g1:
+        assert torch.allclose(g1[k], g2[k], atol=1e-5, rtol=1e-3), k
+    with torch.no_grad():
+        model.attention_net_WSI[3].attention_c.bias += 3.0
+    hz3, A3, g3 = step(x)
+    assert torch.allclose(A3, A1 + 3.0, atol=1e-5)
+    assert torch.allclose(hz3, hz1, atol=1e-6)
+    assert float(g3["attention_net_WSI.3.attention_c.bias"].abs().max()) < 1e-5
+
+
+def test_softmax_spike_forces_rescale():
+    """One instance with a huge score: the online-softmax merge must stay finite and put all the
+    weight on it (M == h of that instance)."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    m = dict(N=3000, gated=True, size="small", K=4, dropout=False, y=1, c=0, alpha=0.0, bias_std=0.05,
+             train=False, seed=4200, x_seed=5200, mask_seed=0)
+    sd, x, _ = cases.path_inputs(m)
+    sd = dict(sd)
+    sd["attention_net_WSI.3.attention_c.weight"] = sd["attention_net_WSI.3.attention_c.weight"] * 400.0
+    model = _load(MIL_Attention_fc_surv_path(gate_path=True, n_classes=4), sd).eval()
+    with torch.no_grad():
+        hz, S, Yh, A = model(path_features=_t(x))
+        M = model(path_features=_t(x), return_features=True)
+    assert torch.isfinite(hz).all() and torch.isfinite(M).all()
+    from oracle import torch_port as tp
+    tsd = tp.to_torch(sd, torch.float64, requires_grad=False)
+    hz_r, S_r, _, A_r, M_r = tp.path_forward(tsd, torch.as_tensor(x).double(), True, False, None)
+    assert float((A_r.max() - A_r.topk(2).values[0, 1])) > 5.0    # the spike really dominates
+    np.testing.assert_allclose(M.cpu().numpy(), M_r.numpy(), atol=2e-4)
+    np.testing.assert_allclose(hz.cpu().numpy(), hz_r.numpy(), atol=1e-4)
+
+
+def test_full_size_50k_properties():
+    """BASELINE size (50k x 1024): linearity of the loss gradient in dM, finite outputs, softmax mass 1.
+    Oracle-free, size-independent checks; a sampled oracle comparison covers the numbers."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    m = dict(N=50000, gated=True, size="small", K=4, dropout=False, y=1, c=0, alpha=0.0, bias_std=0.0,
+             train=False, seed=1, x_seed=1234, mask_seed=0)
+    sd, x, _ = cases.path_inputs(m)
+    model = _load(MIL_Attention_fc_surv_path(gate_path=True, n_classes=4), sd).eval()
+    xt = _t(x)
+    hz, S, Yh, A = model(path_features=xt)
+    loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.], device=DEV))
+    loss.backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    hz, S, Yh, A = model(path_features=xt)
+    loss2 = 3.0 * NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.], device=DEV))
+    loss2.backward()
+    for k, p in model.named_parameters():
+        assert torch.allclose(p.grad, 3.0 * g1[k], rtol=1e-4, atol=1e-7), k
+    # oracle on the same inputs (fp64, ~10 s of CPU)
+    ref = cases.run_path(m)
+    res = dict(hazards=hz.detach().cpu().numpy(), S=S.detach().cpu().numpy(), A_raw=A.detach().cpu().numpy(),
+               loss=float(loss), M=None, grads={k: v.cpu().numpy() for k, v in g1.items()})
+    compare(res, ref, "50k")
