@@ -246,36 +246,54 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   }
 }
 
-// single workgroup: merge the per-group partials
-__global__ __launch_bounds__(256) void pool_merge_kernel(PoolParams p) {
-  __shared__ float red[8];
-  const int tid = threadIdx.x;
+// single workgroup of 1024 threads: merge the per-group partials.
+// Group weights exp(m_g - m) are computed once into LDS; the column sums then run as H columns x
+// (1024/H) group slices of independent, unrolled loads (the first version's serial dependent
+// loop over groups cost 115 us; this one is a few us).
+constexpr int MERGE_MAX_GROUPS = 4096;
+__global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
+  __shared__ float wl[MERGE_MAX_GROUPS];
+  __shared__ float red[32];
+  __shared__ float colred[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stride = 2 + p.H;
   float m = -INFINITY;
-  for (int g = tid; g < p.n_groups; g += 256) m = fmaxf(m, p.partials[(size_t)g * (2 + p.H)]);
+  for (int g = tid; g < p.n_groups; g += 1024) {
+    float mg = p.partials[(size_t)g * stride];
+    wl[g] = mg;
+    m = fmaxf(m, mg);
+  }
   m = wave_max(m);
-  if ((tid & 63) == 0) red[tid >> 6] = m;
+  if (lane == 0) red[wave] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
   float l = 0.f;
-  for (int g = tid; g < p.n_groups; g += 256) {
-    const float* q = p.partials + (size_t)g * (2 + p.H);
-    float mg = q[0];
-    if (mg > -INFINITY) l += q[1] * __expf(mg - m);
+  for (int g = tid; g < p.n_groups; g += 1024) {
+    float mg = wl[g];
+    float w = mg > -INFINITY ? __expf(mg - m) : 0.f;
+    wl[g] = w;
+    l += p.partials[(size_t)g * stride + 1] * w;
   }
   l = wave_sum(l);
-  if ((tid & 63) == 0) red[4 + (tid >> 6)] = l;
+  if (lane == 0) red[16 + wave] = l;
   __syncthreads();
-  l = red[4] + red[5] + red[6] + red[7];
-  const float inv = 1.0f / l;
-  for (int c = tid; c < p.H; c += 256) {
-    float acc = 0.f;
-    for (int g = 0; g < p.n_groups; ++g) {
-      const float* q = p.partials + (size_t)g * (2 + p.H);
-      float mg = q[0];
-      if (mg > -INFINITY) acc += q[2 + c] * __expf(mg - m);
-    }
-    p.M[c] = acc * inv;
+  l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) l += red[16 + i];
+  const int SL = 1024 / p.H;             // group slices (H = 256 -> 4, 512 -> 2, 1024 -> 1)
+  const int c = tid % p.H, sl = tid / p.H;
+  float acc = 0.f;
+  const float* q = p.partials + 2 + c;
+#pragma unroll 8
+  for (int g = sl; g < p.n_groups; g += SL) acc += q[(size_t)g * stride] * wl[g];
+  colred[tid] = acc;
+  __syncthreads();
+  if (tid < p.H) {
+    float s = 0.f;
+    for (int i = 0; i < SL; ++i) s += colred[i * p.H + tid];
+    p.M[tid] = s / l;
   }
   if (tid == 0) { p.stats[0] = m; p.stats[1] = l; }
 }
@@ -348,7 +366,8 @@ int launch_pool(PoolParams p, hipStream_t st) {
   p.rows_per_group = (int)((p.N + p.n_groups - 1) / p.n_groups);
   if (p.rows_per_group > POOL_MAX_ROWS) return MMF_ERR_SHAPE;
   { ProfScope ps("pool_partial_kernel", st); hipLaunchKernelGGL(pool_partial_kernel, dim3(p.n_groups), dim3(256), 0, st, p); }
-  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(1), dim3(256), 0, st, p); }
+  if (p.n_groups > MERGE_MAX_GROUPS) return MMF_ERR_SHAPE;
+  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(1), dim3(1024), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 

@@ -50,7 +50,7 @@ void prof_end(hipStream_t st) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-constexpr int PREP_GROUPS = 1024;
+constexpr int PREP_GROUPS = 512;
 
 struct AmilWs {
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;

@@ -142,42 +142,71 @@ struct LoadM {
 };
 
 // ---- MFMA over one staged chunk ---------------------------------------------------------------
+// Fragments of k-group q+1 are read from LDS into a second register set BEFORE the 4*MB*NB MFMAs of
+// group q are issued, so an LDS read has a whole MFMA block (>= 1024 cycles) to land.  (Left to
+// itself hipcc emitted read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, exposing the LDS latency every 256
+// cycles: 55 % MFMA utilisation on the TN kernel.)  Registers are free here: LDS already limits the
+// kernels to 2 waves per SIMD.
+template <class T>
+struct Frags {
+  float a[T::MB][4];
+  float b[T::NB][4];
+};
+
+template <class T>
+__device__ inline void read_frags(const float* __restrict__ As, const float* __restrict__ Bs, int q,
+                                  int arow, int brow, int hh, Frags<T>& f) {
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb) {
+    if constexpr (T::A_KCONTIG) {
+      float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * q + 4 * hh);
+      f.a[mb][0] = t.x; f.a[mb][1] = t.y; f.a[mb][2] = t.z; f.a[mb][3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.a[mb][j] = As[(8 * q + 4 * hh + j) * T::BM + arow + mb * 32];
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb) {
+    if constexpr (T::B_KCONTIG) {
+      float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * q + 4 * hh);
+      f.b[nb][0] = t.x; f.b[nb][1] = t.y; f.b[nb][2] = t.z; f.b[nb][3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.b[nb][j] = Bs[(8 * q + 4 * hh + j) * T::BN + brow + nb * 32];
+    }
+  }
+}
+
+template <class T>
+__device__ inline void mfma_frags(const Frags<T>& f, f32x16 (&acc)[T::MB][T::NB]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < T::NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][j], f.b[nb][j], acc[mb][nb], 0, 0, 0);
+}
+
 template <class T>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                      f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane) {
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + r;
   const int brow = wn * T::NB * 32 + r;
+  Frags<T> f0, f1;
+  read_frags<T>(As, Bs, 0, arow, brow, hh, f0);
 #pragma unroll
-  for (int q = 0; q < KC / 8; ++q) {
-    float av[T::MB][4], bv[T::NB][4];
-#pragma unroll
-    for (int mb = 0; mb < T::MB; ++mb) {
-      if constexpr (T::A_KCONTIG) {
-        float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * q + 4 * hh);
-        av[mb][0] = t.x; av[mb][1] = t.y; av[mb][2] = t.z; av[mb][3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) av[mb][j] = As[(8 * q + 4 * hh + j) * T::BM + arow + mb * 32];
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < T::NB; ++nb) {
-      if constexpr (T::B_KCONTIG) {
-        float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * q + 4 * hh);
-        bv[nb][0] = t.x; bv[nb][1] = t.y; bv[nb][2] = t.z; bv[nb][3] = t.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[nb][j] = Bs[(8 * q + 4 * hh + j) * T::BN + brow + nb * 32];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mb = 0; mb < T::MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < T::NB; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][j], bv[nb][j], acc[mb][nb], 0, 0, 0);
+  for (int q = 0; q < KC / 8; q += 2) {
+    read_frags<T>(As, Bs, q + 1, arow, brow, hh, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags<T>(f0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 2 < KC / 8) read_frags<T>(As, Bs, q + 2, arow, brow, hh, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags<T>(f1, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

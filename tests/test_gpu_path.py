@@ -210,7 +210,8 @@ def test_full_size_50k_properties():
     loss2 = 3.0 * NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.], device=DEV))
     loss2.backward()
     for k, p in model.named_parameters():
-        assert torch.allclose(p.grad, 3.0 * g1[k], rtol=1e-4, atol=1e-7), k
+        atol = 1e-6 if k.endswith("attention_c.bias") else 1e-7   # d(bc) is pure cancellation noise (analytically 0)
+        assert torch.allclose(p.grad, 3.0 * g1[k], rtol=1e-4, atol=atol), k
     # oracle on the same inputs (fp64, ~10 s of CPU)
     ref = cases.run_path(m)
     res = dict(hazards=hz.detach().cpu().numpy(), S=S.detach().cpu().numpy(), A_raw=A.detach().cpu().numpy(),
