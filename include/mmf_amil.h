@@ -115,6 +115,31 @@ int mmf_nll_surv(const float* hazards, const float* S, const int64_t* Y, const f
 int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_t B,
                  float* loss, float* d_risks, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Small dense layers (any dimensions, batch 1..128) and the Kronecker fusion block.
+ *   replaces SNN_Block (models/model_modules.py:64-68: Linear+SELU+AlphaDropout), the Linear+ReLU+Dropout
+ *   stacks and gating of XlinearFusion (models/model_modules.py:133-178), and the fusion classifiers
+ *   (models/model_mm_attention_mil.py:91,95).
+ *   drop_kind: 0 none, 1 nn.Dropout, 2 nn.AlphaDropout; the mask is the keep-hash of (seed, site, element).
+ * ------------------------------------------------------------------------------------------- */
+int mmf_dense_forward(const float* x, const float* W, const float* bias, int32_t B, int32_t K, int32_t N,
+                      int32_t act, int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                      float* y, void* stream);
+/* dy, y (the forward OUTPUT) -> dx [B x K] (may be NULL), dW [N x K], db [N] (may be NULL);
+ * dpre_scratch: [B x N] floats. */
+int mmf_dense_backward(const float* dy, const float* y, const float* x, const float* W,
+                       int32_t B, int32_t K, int32_t N, int32_t act,
+                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                       float* dpre_scratch, float* dx, float* dW, float* db, void* stream);
+/* o = sigmoid(z) * h (n elements) and its backward. */
+int mmf_gate_mul_forward(const float* z, const float* h, float* o, int32_t n, void* stream);
+int mmf_gate_mul_backward(const float* g, const float* z, const float* h, float* dz, float* dh, int32_t n, void* stream);
+/* out[b] = [o0,1] (x) [o1,1] ((x) [o2,1]) followed by Dropout(drop_p); o_t: [B x dim]; m = 2 or 3 (HOST array of ptrs). */
+int mmf_kron_forward(const float* const* o, int32_t m, int32_t dim, int32_t B,
+                     float drop_p, uint32_t seed, uint32_t site, float* out, void* stream);
+int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t dim, int32_t B,
+                      float drop_p, uint32_t seed, uint32_t site, float* const* d_o, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
  * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
  * records and returns the number of bytes written (or needed when buf == NULL). */

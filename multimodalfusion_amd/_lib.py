@@ -63,6 +63,19 @@ SYMBOLS = {
     "mmf_cox_surv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_dropout_keep_host": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
+    "mmf_dense_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mmf_dense_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_float, C.c_uint32, C.c_uint32,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_gate_mul_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mmf_gate_mul_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p]),
+    "mmf_kron_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mmf_kron_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
     "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),
 }

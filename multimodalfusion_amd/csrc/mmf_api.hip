@@ -14,6 +14,7 @@
 #include "mmf_gemm_core.h"
 #include "mmf_kernels.h"
 #include "mmf_small.h"
+#include "mmf_mlp.h"
 
 namespace mmf {
 
@@ -333,6 +334,59 @@ int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_
   if (!risks || !times || !c || !loss || !d_risks || B < 1) return MMF_ERR_ARG;
   CoxParams p{risks, times, c, B, loss, d_risks};
   return launch_cox(p, static_cast<hipStream_t>(stream));
+}
+
+static DropSpec make_drop(int kind, float p, uint32_t seed, uint32_t site) {
+  DropSpec d;
+  d.kind = p > 0.f ? kind : 0;
+  d.p = p;
+  d.key = drop_key(seed, site);
+  return d;
+}
+
+int mmf_dense_forward(const float* x, const float* W, const float* bias, int32_t B, int32_t K, int32_t N,
+                      int32_t act, int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                      float* y, void* stream) {
+  if (!x || !W || !y || B < 1 || K < 1 || N < 1) return MMF_ERR_ARG;
+  if (act < 0 || act > ACT_SELU || drop_kind < 0 || drop_kind > 2 || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  DenseParams p{x, W, bias, y, B, K, N, act, make_drop(drop_kind, drop_p, seed, site)};
+  return launch_dense_fwd(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_dense_backward(const float* dy, const float* y, const float* x, const float* W,
+                       int32_t B, int32_t K, int32_t N, int32_t act,
+                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                       float* dpre_scratch, float* dx, float* dW, float* db, void* stream) {
+  if (!dy || !y || !x || !W || !dpre_scratch || B < 1 || K < 1 || N < 1) return MMF_ERR_ARG;
+  if (act < 0 || act > ACT_SELU || drop_kind < 0 || drop_kind > 2) return MMF_ERR_ARG;
+  DenseBwdParams p{dy, y, x, W, dpre_scratch, dx, dW, db, B, K, N, act, make_drop(drop_kind, drop_p, seed, site)};
+  return launch_dense_bwd(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_gate_mul_forward(const float* z, const float* h, float* o, int32_t n, void* stream) {
+  if (!z || !h || !o || n < 1) return MMF_ERR_ARG;
+  return launch_gate_mul(z, h, o, n, static_cast<hipStream_t>(stream));
+}
+int mmf_gate_mul_backward(const float* g, const float* z, const float* h, float* dz, float* dh, int32_t n, void* stream) {
+  if (!g || !z || !h || !dz || !dh || n < 1) return MMF_ERR_ARG;
+  return launch_gate_mul_bwd(g, z, h, dz, dh, n, static_cast<hipStream_t>(stream));
+}
+
+int mmf_kron_forward(const float* const* o, int32_t m, int32_t dim, int32_t B,
+                     float drop_p, uint32_t seed, uint32_t site, float* out, void* stream) {
+  if (!o || (m != 2 && m != 3) || dim < 1 || B < 1 || !out) return MMF_ERR_ARG;
+  KronParams p{};
+  for (int i = 0; i < m; ++i) { if (!o[i]) return MMF_ERR_ARG; p.o[i] = o[i]; }
+  p.out = out; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site);
+  return launch_kron_fwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t dim, int32_t B,
+                      float drop_p, uint32_t seed, uint32_t site, float* const* d_o, void* stream) {
+  if (!g || !o || !d_o || (m != 2 && m != 3) || dim < 1 || B < 1) return MMF_ERR_ARG;
+  KronParams p{};
+  for (int i = 0; i < m; ++i) { if (!o[i] || !d_o[i]) return MMF_ERR_ARG; p.o[i] = o[i]; p.d[i] = d_o[i]; }
+  p.g = g; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site);
+  return launch_kron_bwd(p, static_cast<hipStream_t>(stream));
 }
 
 void mmf_profile_enable(int on) {

@@ -1,0 +1,57 @@
+"""Omic self-normalising network head; drop-in for models/model_genomic.py of the reference
+(MaxNet_base ctor :13-39, MaxNet.forward :53-72, state_dict keys fc_omic.{i}.0.*, classifier.*)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.utils import init_max_weights
+from .model_modules import SNN_Block, snn_stack
+
+
+class MaxNet_base(nn.Module):
+    def __init__(self, input_dim: int, model_size_omic: str = "small", bag_loss=None, n_classes: int = 4):
+        super().__init__()
+        self.n_classes = n_classes
+        self.size_dict_omic = {"small": [256, 256], "big": [1024, 256]}
+        self.bag_loss = bag_loss
+        hidden = self.size_dict_omic[model_size_omic]
+        fc_omic = [SNN_Block(dim1=input_dim, dim2=hidden[0])]
+        for i, _ in enumerate(hidden[1:]):
+            fc_omic.append(SNN_Block(dim1=hidden[i], dim2=hidden[i + 1], dropout=0.25))
+        self.fc_omic = nn.Sequential(*fc_omic)
+        if "nll" in self.bag_loss:
+            self.classifier = nn.Linear(hidden[-1], n_classes)
+        else:
+            self.classifier = nn.Linear(hidden[-1], 1)
+        init_max_weights(self)
+
+    def relocate(self):
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.fc_omic = self.fc_omic.to(device)
+        self.classifier = self.classifier.to(device)
+
+    def forward(self, **kwargs):
+        pass
+
+
+class MaxNet(MaxNet_base):
+    def __init__(self, input_dim: int, model_size_omic: str = "small", bag_loss=None, n_classes: int = 4):
+        super().__init__(input_dim, model_size_omic, bag_loss, n_classes)
+
+    def forward(self, **kwargs):
+        x = kwargs["genomic_features"]
+        features = snn_stack(self.fc_omic, x, self.training)
+        if kwargs.get("return_features"):
+            return features
+        if "nll" in self.bag_loss:
+            # The reference unsqueezes to [1 x B x K] and then takes topk / cumprod over dim=1, i.e. over the
+            # BATCH axis (model_genomic.py:63-69).  Reproduced as is: hazards come from the HIP dense kernel,
+            # the two degenerate axis ops are plain tensor ops on a [1 x B x K] view.
+            hazards = ops.dense(features, self.classifier.weight, self.classifier.bias, act="sigmoid").unsqueeze(0)
+            Y_hat = torch.topk(hazards.detach(), 1, dim=1)[1]   # sigmoid is monotone: same indices as topk(logits)
+            S = torch.cumprod(1 - hazards, dim=1)
+            return hazards, S, Y_hat, None
+        risk = ops.dense(features, self.classifier.weight, self.classifier.bias).squeeze()
+        return risk, None, None, None

@@ -1,0 +1,154 @@
+"""Multimodal (radiology + pathology + omic) attention-MIL with concat / tensor fusion; drop-in for
+models/model_mm_attention_mil.py of the reference (ctor signatures :19-23 / :118-121, forward :128-200,
+state_dict keys of Appendix B).
+
+The reference class cannot be constructed or run as shipped.  What this module does
+about each defect -- the signature and the mathematics are kept, nothing else is changed:
+  * `gate_omic=` is accepted by the subclass and not forwarded (the reference forwards it to a base ctor
+    without that parameter -> TypeError, :124);
+  * the fused width uses size_WSI (the reference names an undefined `size_path`, :83);
+  * `genomic_features` may be [G] (what the forward expects, :165) or [1 x G] (what the collate delivers);
+  * radio_fusion='tensor' raises NotImplementedError (the reference calls an attribute that is never
+    defined, :141);
+  * return_features=True returns the fused embedding (the reference raises NameError, :196-198).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.utils import initialize_weights
+from .model_modules import Attn_Net, Attn_Net_Gated, SNN_Block, XlinearFusion, amil_stack, snn_stack
+
+
+class MM_MIL_Attention_fc(nn.Module):
+    def __init__(self, input_dim: int = 80, radio_fusion="concat", fusion="tensor", gate=True, gate_path=True,
+                 gate_radio=True, dropout=True, model_size_radio: str = "small", model_size_wsi: str = "small",
+                 model_size_omic: str = "small", n_classes=4, modalities=["T1", "T2", "T1Gd", "FLAIR"],
+                 mode="radio_path_omic"):
+        super().__init__()
+        self.radio_fusion = radio_fusion
+        self.fusion = fusion
+        self.n_classes = n_classes
+        self.size_dict_radio = {"small": [1024, 256, 256], "big": [1024, 256, 384]}
+        self.size_dict_WSI = {"small": [1024, 256, 256], "big": [1024, 256, 384]}
+        self.size_dict_omic = {"small": [256, 256], "big": [1024, 256]}
+        self.modalities = modalities
+        self.mode = mode
+
+        size_omic = self.size_dict_omic[model_size_omic]
+        fc_omic = [SNN_Block(dim1=input_dim, dim2=size_omic[0])]
+        for i, _ in enumerate(size_omic[1:]):
+            fc_omic.append(SNN_Block(dim1=size_omic[i], dim2=size_omic[i + 1], dropout=0.25))
+        self.fc_omic = nn.Sequential(*fc_omic)
+
+        size_radio = self.size_dict_radio[model_size_radio]
+        fc_radio = [nn.Linear(size_radio[0], size_radio[1]), nn.ReLU(), nn.Dropout(0.25)]
+        if gate_radio:
+            att = Attn_Net_Gated(L=size_radio[1], D=size_radio[2], dropout=dropout, n_classes=1)
+        else:
+            att = Attn_Net(L=size_radio[1], D=size_radio[2], dropout=dropout, n_classes=1)
+        fc_radio.append(att)
+        self.attention_net_radio = nn.Sequential(*fc_radio)
+
+        if self.radio_fusion == "tensor":
+            raise NotImplementedError("radio_fusion='tensor' is unusable in the reference and not provided")
+        elif self.radio_fusion == "concat":
+            self.reduce_dim = nn.Linear(size_radio[0] * len(self.modalities), size_radio[0])
+
+        size_WSI = self.size_dict_WSI[model_size_wsi]
+        fc_WSI = [nn.Linear(size_WSI[0], size_WSI[1]), nn.ReLU(), nn.Dropout(0.25)]
+        if gate_path:
+            att = Attn_Net_Gated(L=size_WSI[1], D=size_WSI[2], dropout=dropout, n_classes=1)
+        else:
+            att = Attn_Net(L=size_WSI[1], D=size_WSI[2], dropout=dropout, n_classes=1)
+        fc_WSI.append(att)
+        self.attention_net_WSI = nn.Sequential(*fc_WSI)
+
+        classifier_size = 0
+        n_modalities = 0
+        if "radio" in mode:
+            classifier_size += size_radio[1]
+            n_modalities += 1
+        if "path" in mode:
+            classifier_size += size_WSI[1]
+            n_modalities += 1
+        if "omic" in mode:
+            classifier_size += size_omic[1]
+            n_modalities += 1
+
+        if self.fusion == "tensor":
+            self.mm = XlinearFusion(dim=256, scale_dim=16, mmhid1=512, mmhid2=512, num_modalities=n_modalities,
+                                    gate=gate, skip=1)
+            self.classifier = nn.Sequential(*[nn.Linear(512, 256), nn.ReLU(), nn.Dropout(0.25),
+                                              nn.Linear(256, n_classes)])
+        elif self.fusion == "concat":
+            self.classifier = nn.Linear(classifier_size, n_classes)
+        initialize_weights(self)
+
+    def relocate(self):
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.fc_omic = self.fc_omic.to(device)
+        self.attention_net_radio = self.attention_net_radio.to(device)
+        self.attention_net_WSI = self.attention_net_WSI.to(device)
+        self.classifier = self.classifier.to(device)
+        if self.fusion == "tensor":
+            self.mm = self.mm.to(device)
+        if self.radio_fusion == "concat":
+            self.reduce_dim = self.reduce_dim.to(device)
+
+    def forward(self, h, return_features=False, attention_only=False):
+        pass
+
+
+class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
+    def __init__(self, input_dim: int = 80, radio_fusion: str = "concat", fusion: str = "tensor", gate=True,
+                 gate_path=True, gate_omic=True, gate_radio=True, model_size_radio="small",
+                 model_size_wsi: str = "small", model_size_omic="small", dropout=False, n_classes=4,
+                 mode="radio_path_omic"):
+        super().__init__(input_dim=input_dim, radio_fusion=radio_fusion, fusion=fusion, gate=gate,
+                         gate_path=gate_path, gate_radio=gate_radio, model_size_radio="small",
+                         model_size_wsi=model_size_wsi, model_size_omic=model_size_omic, dropout=dropout,
+                         n_classes=n_classes, mode=mode)
+
+    def forward(self, **kwargs):
+        A_raw = {}
+        if "radio" in self.mode:
+            h_radio = [kwargs[m] for m in self.modalities]
+            if len(self.modalities) > 1:
+                h_radio = ops.linear_cat(h_radio, self.reduce_dim.weight, self.reduce_dim.bias)
+            else:
+                h_radio = h_radio[0]
+            M_radio, A_raw["radiology"] = amil_stack(self.attention_net_radio, h_radio, self.training)
+        if "path" in self.mode:
+            M_path, A_raw["pathology"] = amil_stack(self.attention_net_WSI, kwargs["path_features"], self.training)
+        if "omic" in self.mode:
+            X = kwargs["genomic_features"]
+            if X.dim() == 1:
+                X = X.unsqueeze(0)
+            O = snn_stack(self.fc_omic, X, self.training)
+
+        has = lambda k: k in self.mode
+        if has("radio") and has("path") and not has("omic"):
+            v_list = [M_radio, M_path]
+        elif has("radio") and has("omic") and not has("path"):
+            v_list = [M_radio, O]
+        elif has("omic") and has("path") and not has("radio"):
+            v_list = [O, M_path]
+        else:
+            v_list = [M_radio, M_path, O]
+
+        if self.fusion == "tensor":
+            seed = ops.next_dropout_seed() if self.training else 0
+            MM = self.mm(v_list=v_list, seed=seed)
+            c0, c3 = self.classifier[0], self.classifier[3]
+            hid = ops.dense(MM, c0.weight, c0.bias, act="relu", drop_kind="dropout" if self.training else "none",
+                            drop_p=self.classifier[2].p if self.training else 0.0, seed=seed, site=11)
+            hazards, S, Y_hat = ops.surv_head(hid, c3.weight, c3.bias)
+        else:
+            MM = torch.cat(v_list, dim=1)
+            hazards, S, Y_hat = ops.surv_head(MM, self.classifier.weight, self.classifier.bias)
+        if kwargs.get("return_features"):
+            return MM
+        return hazards, S, Y_hat, A_raw

@@ -233,3 +233,105 @@ class CoxSurvFn(torch.autograd.Function):
 
 def cox_surv(risks, times, c):
     return CoxSurvFn.apply(risks, times, c)
+
+
+DROP_KIND = {"none": 0, "dropout": 1, "alpha": 2}
+
+
+class DenseFn(torch.autograd.Function):
+    """y = drop(act(x @ W.T + b)) for small / odd-shaped layers (SNN blocks, fusion MLPs, classifiers)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, drop_kind, drop_p, seed, site):
+        x, W, b = _f32c(x), _f32c(W), _f32c(b)
+        B, K = x.shape
+        N = W.shape[0]
+        if W.shape[1] != K:
+            raise _lib.MmfError(f"dense: weight {tuple(W.shape)} does not match input {tuple(x.shape)}")
+        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        check(lib().mmf_dense_forward(ptr(x), ptr(W), ptr(b), B, K, N, ACT[act], DROP_KIND[drop_kind], float(drop_p),
+                                      int(seed) & 0xFFFFFFFF, int(site), ptr(y), stream_ptr()), "mmf_dense_forward")
+        ctx.cfg = (act, drop_kind, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), b is not None)
+        ctx.save_for_backward(x, W, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W, y = ctx.saved_tensors
+        act, drop_kind, drop_p, seed, site, has_bias = ctx.cfg
+        gy = _f32c(gy)
+        B, K = x.shape
+        N = W.shape[0]
+        dpre = torch.empty_like(y)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None
+        check(lib().mmf_dense_backward(ptr(gy), ptr(y), ptr(x), ptr(W), B, K, N, ACT[act], DROP_KIND[drop_kind],
+                                       drop_p, seed, site, ptr(dpre), ptr(dx), ptr(dW), ptr(db), stream_ptr()),
+              "mmf_dense_backward")
+        return dx, dW, db, None, None, None, None, None
+
+
+def dense(x, W, b, act="none", drop_kind="none", drop_p=0.0, seed=0, site=0):
+    return DenseFn.apply(x, W, b, act, drop_kind, drop_p, seed, site)
+
+
+class GateMulFn(torch.autograd.Function):
+    """sigmoid(z) * h (models/model_modules.py:163)."""
+
+    @staticmethod
+    def forward(ctx, z, h):
+        z, h = _f32c(z), _f32c(h)
+        o = torch.empty_like(h)
+        check(lib().mmf_gate_mul_forward(ptr(z), ptr(h), ptr(o), h.numel(), stream_ptr()), "mmf_gate_mul_forward")
+        ctx.save_for_backward(z, h)
+        return o
+
+    @staticmethod
+    def backward(ctx, g):
+        z, h = ctx.saved_tensors
+        g = _f32c(g)
+        dz, dh = torch.empty_like(z), torch.empty_like(h)
+        check(lib().mmf_gate_mul_backward(ptr(g), ptr(z), ptr(h), ptr(dz), ptr(dh), h.numel(), stream_ptr()),
+              "mmf_gate_mul_backward")
+        return dz, dh
+
+
+def gate_mul(z, h):
+    return GateMulFn.apply(z, h)
+
+
+class KronFn(torch.autograd.Function):
+    """[o0,1] (x) [o1,1] ((x) [o2,1]) + post-fusion Dropout (models/model_modules.py:164-171)."""
+
+    @staticmethod
+    def forward(ctx, drop_p, seed, site, *os_):
+        os_ = [_f32c(o) for o in os_]
+        m = len(os_)
+        B, dim = os_[0].shape
+        total = (dim + 1) ** m
+        out = torch.empty((B, total), dtype=torch.float32, device=os_[0].device)
+        arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
+        check(lib().mmf_kron_forward(arr, m, dim, B, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(out),
+                                     stream_ptr()), "mmf_kron_forward")
+        ctx.cfg = (float(drop_p), int(seed) & 0xFFFFFFFF, int(site))
+        ctx.save_for_backward(*os_)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        os_ = list(ctx.saved_tensors)
+        drop_p, seed, site = ctx.cfg
+        m = len(os_)
+        B, dim = os_[0].shape
+        g = _f32c(g)
+        ds = [torch.empty_like(o) for o in os_]
+        arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
+        darr = (C.c_void_p * m)(*[ptr(d) for d in ds])
+        check(lib().mmf_kron_backward(ptr(g), arr, m, dim, B, drop_p, seed, site, darr, stream_ptr()),
+              "mmf_kron_backward")
+        return (None, None, None) + tuple(ds)
+
+
+def kron_ones(os_, drop_p=0.0, seed=0, site=0):
+    return KronFn.apply(drop_p, seed, site, *os_)
