@@ -144,6 +144,8 @@ int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t 
  * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
  * records and returns the number of bytes written (or needed when buf == NULL). */
 void mmf_profile_enable(int on);
+/* Diagnostic builds only (-DMMF_STAMPS): summed s_memtime phase cycles of the GEMM main loop; zeros otherwise. */
+void mmf_debug_stamps(int which, unsigned long long* out8);
 int mmf_profile_dump(char* buf, size_t buf_bytes);
 
 /* Host-side restatement of the device dropout keep-hash (1 = kept).  For tests / mask inspection only. */

@@ -77,6 +77,7 @@ SYMBOLS = {
     "mmf_kron_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                     C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
+    "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),
     "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
 

@@ -20,7 +20,7 @@ HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_kernels.h", "mmf_small.h", "m
            os.path.join("..", "..", "include", "mmf_amil.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable"]
+         "-Wno-unused-variable", "-Wno-unused-result"] + os.environ.get("MMF_EXTRA_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -13,6 +13,8 @@
 //                   k >= D : ds_i Wc[k'] a_d b (1 - b) m_b       (d pre-sigmoid), k' = k - D
 //            ungated       : ds_i Wc[k] (1 - a^2) m_a
 // with a_d = a m_a, b_d = b m_b the dropped activations (m = keep/(1-p); m = 1 in eval).
+#include <cstdlib>
+
 #include "mmf_gemm_core.h"
 #include "mmf_kernels.h"
 
@@ -322,14 +324,26 @@ __device__ inline void tn_store(const TnProblem& q, int split, int tm, int tn, f
 template <class T>
 __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   extern __shared__ __align__(16) float lds[];
+  // XCD-aware block -> (split, tile) map.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only):
+  // every tile of one K-split is put on ONE XCD, so the operand rows of that split are fetched into that
+  // XCD's L2 once and shared by all its tiles, instead of once per tile through eight different L2s
+  // (the first version moved ~1.3 GB per launch through the fabric and ran at 55 % MFMA utilisation).
   const int b = blockIdx.x;
+  int split, tg;
+  if (p.xcd_map) {
+    const int xcd = b & 7, idx = b >> 3;
+    split = xcd + 8 * (idx / p.total_tiles);
+    tg = idx % p.total_tiles;
+  } else {
+    split = b / p.total_tiles;
+    tg = b - split * p.total_tiles;
+  }
+  if (split >= p.splits) return;
   int pi = 0;
   for (int i = 1; i < p.nprob; ++i)
-    if (b >= p.prob[i].block_begin) pi = i;
+    if (tg >= p.prob[i].block_begin) pi = i;
   const TnProblem& q = p.prob[pi];
-  const int local = b - q.block_begin;
-  const int tiles = q.tiles_m * q.tiles_n;
-  const int split = local / tiles, t = local - split * tiles;
+  const int t = tg - q.block_begin;
   const int tm = t / q.tiles_n, tn = t - tm * q.tiles_n;
   const int64_t kb64 = (int64_t)split * p.k_per_split;
   const int kbase = (int)(kb64 < p.K ? kb64 : p.K);
@@ -465,11 +479,15 @@ int launch_tn(TnParams p, hipStream_t st) {
     if (q.kind == TN_A_GATE && (p.g.D % T::BM != 0)) return MMF_ERR_SHAPE;   // a tile never straddles the a|b halves
     q.tiles_m = (q.M + T::BM - 1) / T::BM;
     q.tiles_n = (q.Ncols + T::BN - 1) / T::BN;
-    q.block_begin = blocks;
-    blocks += q.tiles_m * q.tiles_n * p.splits;
+    q.block_begin = blocks;          // first global tile index of this problem
+    blocks += q.tiles_m * q.tiles_n;
   }
   if (blocks == 0) return MMF_OK;
-  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, blocks, st);
+  p.total_tiles = blocks;
+  static const int env_xcd = getenv("MMF_TN_XCD") ? atoi(getenv("MMF_TN_XCD")) : -1;
+  p.xcd_map = env_xcd >= 0 ? env_xcd : 0;
+  const int grid = (p.xcd_map ? 8 * ((p.splits + 7) / 8) : p.splits) * blocks;
+  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
 }
 
 int launch_reduce(ReduceParams p, hipStream_t st) {
@@ -481,6 +499,17 @@ int launch_reduce(ReduceParams p, hipStream_t st) {
   if (blocks == 0) return MMF_OK;
   { ProfScope ps("reduce_kernel", st); hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(256), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// diagnostic: read and clear this translation unit's phase stamps (zeros unless built with -DMMF_STAMPS)
+void debug_stamps_bwd(unsigned long long* out8) {
+#ifdef MMF_STAMPS
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+#else
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+#endif
 }
 
 }  // namespace mmf

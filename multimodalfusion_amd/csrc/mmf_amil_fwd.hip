@@ -371,4 +371,15 @@ int launch_pool(PoolParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+// diagnostic: read and clear this translation unit's phase stamps (zeros unless built with -DMMF_STAMPS)
+void debug_stamps_fwd(unsigned long long* out8) {
+#ifdef MMF_STAMPS
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+#else
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+#endif
+}
+
 }  // namespace mmf

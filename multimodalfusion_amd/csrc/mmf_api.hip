@@ -2,6 +2,7 @@
 // No allocation, no host synchronisation, no global mutable state except the (mutex-guarded)
 // "dynamic LDS attribute already set" set.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -74,6 +75,8 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated) {
   w.mstk = gated ? 2 * D : D;
   const int tiles = ((H + 127) / 128) * ((L + 127) / 128) + ((w.mstk + 127) / 128) * ((H + 127) / 128);
   int splits = 512 / tiles;
+  static const int env_splits = getenv("MMF_TN_SPLITS") ? atoi(getenv("MMF_TN_SPLITS")) : 0;   // tuning override
+  if (env_splits > 0) splits = env_splits;
   const int64_t max_splits = (N + 127) / 128;
   if (splits > max_splits) splits = (int)max_splits;
   if (splits < 1) splits = 1;
@@ -387,6 +390,11 @@ int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t 
   for (int i = 0; i < m; ++i) { if (!o[i] || !d_o[i]) return MMF_ERR_ARG; p.o[i] = o[i]; p.d[i] = d_o[i]; }
   p.g = g; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site);
   return launch_kron_bwd(p, static_cast<hipStream_t>(stream));
+}
+
+/* diagnostic builds only (-DMMF_STAMPS): which = 0 forward TU, 1 backward TU; out8 = {load, mfma, store, barrier cycles, chunks} */
+void mmf_debug_stamps(int which, unsigned long long* out8) {
+  if (which == 0) debug_stamps_fwd(out8); else debug_stamps_bwd(out8);
 }
 
 void mmf_profile_enable(int on) {

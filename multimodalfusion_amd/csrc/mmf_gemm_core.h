@@ -213,6 +213,23 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
 // ---- double-buffered main loop ---------------------------------------------------------------
 // Loader concept: load(kt) issues the global loads of chunk kt into the loader's registers,
 // store(lds) writes them (possibly transformed) into the operand's LDS image.
+// Diagnostic build only (-DMMF_STAMPS): s_memtime phase stamps of the main loop, summed per wave into a
+// per-translation-unit device array that no kernel reads (guide: "In-kernel stamps").  The shipped
+// library is built without the macro and contains no stamp.
+#ifdef MMF_STAMPS
+static __device__ unsigned long long g_stamps[8];
+__device__ inline unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define MMF_STAMP(var) unsigned long long var = stamp_now()
+#else
+#define MMF_STAMP(var)
+#endif
+
 template <class T, class LA, class LB>
 __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,6 +241,9 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
   if (nk <= 0) return;
+#ifdef MMF_STAMPS
+  unsigned long long s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0;
+#endif
   la.load(0);
   lb.load(0);
   la.store(lds);
@@ -233,17 +253,32 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     float* cur = lds + (kt & 1) * T::STAGE_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * T::STAGE_FLOATS;
     const bool more = kt + 1 < nk;
+    MMF_STAMP(t0);
     if (more) {
       la.load(kt + 1);
       lb.load(kt + 1);
     }
+    MMF_STAMP(t1);
     compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane);
+    MMF_STAMP(t2);
     if (more) {
       la.store(nxt);
       lb.store(nxt + T::A_FLOATS);
     }
+    MMF_STAMP(t3);
     __syncthreads();
+    MMF_STAMP(t4);
+#ifdef MMF_STAMPS
+    s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
+#endif
   }
+#ifdef MMF_STAMPS
+  if (lane == 0) {
+    atomicAdd(&g_stamps[0], s_load); atomicAdd(&g_stamps[1], s_mfma);
+    atomicAdd(&g_stamps[2], s_store); atomicAdd(&g_stamps[3], s_bar);
+    atomicAdd(&g_stamps[4], (unsigned long long)nk);
+  }
+#endif
 }
 
 // visit every accumulator element this lane owns: f(row_in_tile, col_in_tile, value)

@@ -100,6 +100,8 @@ struct TnParams {
   int nprob;
   int64_t K;               // number of instances (rows of A and B)
   int splits, k_per_split; // k_per_split is a multiple of KC
+  int total_tiles;         // tiles over all problems (set by launch_tn)
+  int xcd_map;             // 1: all tiles of a split on one XCD
   GateBwdCtx g;
 };
 
@@ -126,6 +128,8 @@ int launch_tn(TnParams p, hipStream_t st);
 int launch_nn(NnParams p, hipStream_t st);
 int launch_reduce(ReduceParams p, hipStream_t st);
 int set_dyn_lds(const void* kern, int bytes);
+void debug_stamps_fwd(unsigned long long* out8);
+void debug_stamps_bwd(unsigned long long* out8);
 
 // Optional per-kernel timing with HIP events on the launch stream (off by default; enabled by
 // mmf_profile_enable() for bench.py's roofline leg).  No cost when disabled.
