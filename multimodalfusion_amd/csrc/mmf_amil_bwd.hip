@@ -77,37 +77,42 @@ template <int ROWS, int NT>
 struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   using Map = KMap<ROWS, NT>;
   GateBwdCtx g;
-  int row0, nrows, tid, part, d0;
+  rsrc_t ra, rb, rwc;
+  int row0, tid, part, d0;
   uint32_t thr;
   float dscale;
+  unsigned voff[Map::NV];
   float dsr[Map::NV];
-  float4 ra[Map::NV], rb[Map::NV], wc4;
-  __device__ inline void init(const GateBwdCtx& g_, int row0_, int nrows_) {
-    g = g_; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+  float4 ra4[Map::NV], rb4[Map::NV], wc4;
+  __device__ inline void init(const GateBwdCtx& g_, int row0_, int nrows) {
+    g = g_; row0 = row0_; tid = threadIdx.x;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const unsigned bytes = (unsigned)nrows * (unsigned)g.D * 4u;
+    ra = make_rsrc(g.a, bytes);
+    rb = make_rsrc(g.gated ? g.b : g.a, bytes);
+    rwc = make_rsrc(g.Wc, (unsigned)g.D * 4u);
+    rsrc_t rds = make_rsrc(g.ds, (unsigned)nrows * 4u);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
       int rr = row0 + Map::row(tid, i);
-      float v = g.ds[rr < nrows ? rr : nrows - 1];
-      dsr[i] = (Map::valid(tid, i) && rr < nrows) ? v : 0.f;
+      bool ok = Map::valid(tid, i) && rr < nrows;
+      voff[i] = ok ? ((unsigned)rr * (unsigned)g.D + 4u * Map::c4(tid, i)) * 4u : OOB;
+      dsr[i] = bld1(rds, ok ? (unsigned)rr * 4u : OOB, 0);     // rows beyond the bag: ds = 0 => dP = 0
     }
   }
   __device__ inline void load(int kt) {
     const int nka = g.D / KC;
     part = kt >= nka ? 1 : 0;
     d0 = (kt - part * nka) * KC;
-    const int c = d0 + 4 * (tid & 7);
-    wc4 = ld4(g.Wc + c);
+    const unsigned soff = (unsigned)d0 * 4u;
+    wc4 = bld4(rwc, 16u * (tid & 7), soff);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int rr = row0 + Map::row(tid, i);
-      size_t o = (size_t)(rr < nrows ? rr : nrows - 1) * g.D + c;
-      ra[i] = ld4(g.a + o);
-      rb[i] = ld4((g.gated ? g.b : g.a) + o);
+      ra4[i] = bld4(ra, voff[i], soff);
+      rb4[i] = bld4(rb, voff[i], soff);
     }
   }
-  // rows beyond the bag have ds == 0 (init), so their dP is exactly 0 whatever a/b were loaded
   __device__ inline void store(float* lds) const {
     const int c = d0 + 4 * (tid & 7);
 #pragma unroll
@@ -117,10 +122,10 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
       uint32_t idx = (uint32_t)rr * (uint32_t)g.D + (uint32_t)c;
       float dummy;
       float4 o;
-      o.x = gate_dp(g, part, ra[i].x, rb[i].x, wc4.x, dsr[i], idx + 0, thr, dscale, dummy);
-      o.y = gate_dp(g, part, ra[i].y, rb[i].y, wc4.y, dsr[i], idx + 1, thr, dscale, dummy);
-      o.z = gate_dp(g, part, ra[i].z, rb[i].z, wc4.z, dsr[i], idx + 2, thr, dscale, dummy);
-      o.w = gate_dp(g, part, ra[i].w, rb[i].w, wc4.w, dsr[i], idx + 3, thr, dscale, dummy);
+      o.x = gate_dp(g, part, ra4[i].x, rb4[i].x, wc4.x, dsr[i], idx + 0, thr, dscale, dummy);
+      o.y = gate_dp(g, part, ra4[i].y, rb4[i].y, wc4.y, dsr[i], idx + 1, thr, dscale, dummy);
+      o.z = gate_dp(g, part, ra4[i].z, rb4[i].z, wc4.z, dsr[i], idx + 2, thr, dscale, dummy);
+      o.w = gate_dp(g, part, ra4[i].w, rb4[i].w, wc4.w, dsr[i], idx + 3, thr, dscale, dummy);
       st4(lds + Map::lds(tid, i), o);
     }
   }
@@ -130,27 +135,32 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
 template <int ROWS, int NT>
 struct LoadWab_M {
   using Map = MMap<ROWS, NT>;
-  const float *Wa, *Wb;
-  int H, D, col0, tid;
+  rsrc_t ra, rb;
+  int D, tid;
+  unsigned hb;
+  unsigned voff[Map::NV];
   float4 r[Map::NV];
-  __device__ inline void init(const float* wa, const float* wb, int H_, int D_, int col0_) {
-    Wa = wa; Wb = wb; H = H_; D = D_; col0 = col0_; tid = threadIdx.x;
-  }
-  __device__ inline void load(int kt) {
+  __device__ inline void init(const float* wa, const float* wb, int H, int D_, int col0) {
+    D = D_; tid = threadIdx.x; hb = (unsigned)H * 4u;
+    ra = make_rsrc(wa, (unsigned)D * hb);
+    rb = make_rsrc(wb ? wb : wa, (unsigned)D * hb);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int k = kt * KC + Map::krow(tid, i);
       int c = col0 + 4 * Map::c4(tid, i);
-      const float* W = k < D ? Wa + (size_t)k * H : Wb + (size_t)(k - D) * H;
-      r[i] = ld4(W + (c < H ? c : H - 4));
+      voff[i] = (Map::valid(tid, i) && c < H) ? (unsigned)Map::krow(tid, i) * hb + (unsigned)c * 4u : OOB;
     }
+  }
+  __device__ inline void load(int kt) {     // a chunk never straddles the Wa | Wb boundary (D % KC == 0)
+    const int k0 = kt * KC;
+    const bool second = k0 >= D;
+    const unsigned soff = (unsigned)(k0 - (second ? D : 0)) * hb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(second ? rb : ra, voff[i], soff);
   }
   __device__ inline void store(float* lds) const {
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      int c = col0 + 4 * Map::c4(tid, i);
-      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), c < H ? r[i] : zero4());
-    }
+    for (int i = 0; i < Map::NV; ++i)
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
 };
 
@@ -206,33 +216,35 @@ __global__ __launch_bounds__(T::NT) void gemm_nn_kernel(NnParams p) {
 template <int ROWS, int NT>
 struct LoadA_M_Plain {
   using Map = MMap<ROWS, NT>;
-  const float* src;
-  int ld, col0, ncols, kbase, kmax, tid, kt_loaded;
+  rsrc_t rs;
+  unsigned ldb, kbase_b;
+  int tid;
   bool do_sum;
+  unsigned voff[Map::NV];
   float4 r[Map::NV];
   float4 csum;
-  __device__ inline void init(const float* s, int ld_, int col0_, int ncols_, int kbase_, int kmax_, bool do_sum_) {
-    src = s; ld = ld_; col0 = col0_; ncols = ncols_; kbase = kbase_; kmax = kmax_; tid = threadIdx.x;
-    do_sum = do_sum_; csum = zero4(); kt_loaded = 0;
-  }
-  __device__ inline void load(int kt) {
-    kt_loaded = kt;
+  __device__ inline void init(const float* s, int ld, int col0, int ncols, int kbase, int kmax, bool do_sum_) {
+    tid = threadIdx.x; do_sum = do_sum_; csum = zero4();
+    rs = make_rsrc(s, (unsigned)(kmax > 0 ? kmax : 0) * (unsigned)ld * 4u);
+    ldb = (unsigned)ld * 4u;
+    kbase_b = (unsigned)kbase * ldb;
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int k = kbase + kt * KC + Map::krow(tid, i);
       int c = col0 + 4 * Map::c4(tid, i);
-      r[i] = ld4(src + (size_t)(k < kmax ? k : kmax - 1) * ld + (c < ncols ? c : ncols - 4));
+      voff[i] = (Map::valid(tid, i) && c < ncols) ? (unsigned)Map::krow(tid, i) * ldb + (unsigned)c * 4u : OOB;
     }
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = kbase_b + (unsigned)(kt * KC) * ldb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(rs, voff[i], soff);
   }
   __device__ inline void store(float* lds) {
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
       if (!Map::valid(tid, i)) continue;
-      int k = kbase + kt_loaded * KC + Map::krow(tid, i);
-      int c = col0 + 4 * Map::c4(tid, i);
-      float4 v = (k < kmax && c < ncols) ? r[i] : zero4();
-      st4(lds + Map::lds(tid, i), v);
-      if (do_sum) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+      st4(lds + Map::lds(tid, i), r[i]);
+      if (do_sum) { csum.x += r[i].x; csum.y += r[i].y; csum.z += r[i].z; csum.w += r[i].w; }   // out-of-range reads are 0
     }
   }
 };
@@ -242,36 +254,46 @@ struct LoadA_M_Gate {   // A[k = instance][m] = dP over the stacked (d pre-tanh 
   using Map = MMap<ROWS, NT>;
   static_assert(NT % Map::VPR == 0, "a thread must own the same columns in every vector slot");
   GateBwdCtx g;
-  int part, d0, kbase, kmax, tid, kt_loaded;
+  rsrc_t ra, rb, rds;
+  int part, d0, kbase, tid, kt_loaded;
   bool do_sum;
   uint32_t thr;
   float dscale;
-  float4 ra[Map::NV], rb[Map::NV], wc4;
+  unsigned db;
+  unsigned voff[Map::NV], voff_ds[Map::NV];
+  float4 ra4[Map::NV], rb4[Map::NV], wc4;
   float dsr[Map::NV];
   float4 csum, csum2;   // column sums of dP (bias grads) and of ds.a_d.b_d (dWc)
-  __device__ inline void init(const GateBwdCtx& g_, int col0, int kbase_, int kmax_, bool do_sum_) {
-    g = g_; kbase = kbase_; kmax = kmax_; tid = threadIdx.x; do_sum = do_sum_;
+  __device__ inline void init(const GateBwdCtx& g_, int col0, int kbase_, int kmax, bool do_sum_) {
+    g = g_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
     part = col0 >= g.D ? 1 : 0;
     d0 = col0 - part * g.D;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     csum = zero4(); csum2 = zero4();
-    int c = d0 + 4 * Map::c4(tid, 0);
-    wc4 = ld4(g.Wc + (c < g.D ? c : g.D - 4));
-    if (c >= g.D) wc4 = zero4();
+    db = (unsigned)g.D * 4u;
+    const unsigned rows = (unsigned)(kmax > 0 ? kmax : 0);
+    ra = make_rsrc(g.a, rows * db);
+    rb = make_rsrc(g.gated ? g.b : g.a, rows * db);
+    rds = make_rsrc(g.ds, rows * 4u);
+    const int c = d0 + 4 * Map::c4(tid, 0);
+    wc4 = bld4(make_rsrc(g.Wc, db), c < g.D ? (unsigned)c * 4u : OOB, 0);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      bool ok = Map::valid(tid, i) && c < g.D;
+      voff[i] = ok ? (unsigned)Map::krow(tid, i) * db + (unsigned)c * 4u : OOB;
+      voff_ds[i] = ok ? (unsigned)Map::krow(tid, i) * 4u : OOB;
+    }
     kt_loaded = 0;
   }
   __device__ inline void load(int kt) {
     kt_loaded = kt;
-    const int c = d0 + 4 * Map::c4(tid, 0);
+    const unsigned k0 = (unsigned)(kbase + kt * KC);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int k = kbase + kt * KC + Map::krow(tid, i);
-      int kc = k < kmax ? k : kmax - 1;
-      size_t o = (size_t)kc * g.D + (c < g.D ? c : g.D - 4);
-      ra[i] = ld4(g.a + o);
-      rb[i] = ld4((g.gated ? g.b : g.a) + o);
-      dsr[i] = g.ds[kc];
+      ra4[i] = bld4(ra, voff[i], k0 * db);
+      rb4[i] = bld4(rb, voff[i], k0 * db);
+      dsr[i] = bld1(rds, voff_ds[i], k0 * 4u);    // 0 beyond the split's last instance => dP = 0 there
     }
   }
   __device__ inline void store(float* lds) {
@@ -281,12 +303,12 @@ struct LoadA_M_Gate {   // A[k = instance][m] = dP over the stacked (d pre-tanh 
       if (!Map::valid(tid, i)) continue;
       int k = kbase + kt_loaded * KC + Map::krow(tid, i);
       uint32_t idx = (uint32_t)k * (uint32_t)g.D + (uint32_t)c;
-      const float dsv = (k < kmax && c < g.D) ? dsr[i] : 0.f;   // out-of-range rows/cols contribute exactly 0
+      const float dsv = dsr[i];
       float4 o, w;
-      o.x = gate_dp(g, part, ra[i].x, rb[i].x, wc4.x, dsv, idx + 0, thr, dscale, w.x);
-      o.y = gate_dp(g, part, ra[i].y, rb[i].y, wc4.y, dsv, idx + 1, thr, dscale, w.y);
-      o.z = gate_dp(g, part, ra[i].z, rb[i].z, wc4.z, dsv, idx + 2, thr, dscale, w.z);
-      o.w = gate_dp(g, part, ra[i].w, rb[i].w, wc4.w, dsv, idx + 3, thr, dscale, w.w);
+      o.x = gate_dp(g, part, ra4[i].x, rb4[i].x, wc4.x, dsv, idx + 0, thr, dscale, w.x);
+      o.y = gate_dp(g, part, ra4[i].y, rb4[i].y, wc4.y, dsv, idx + 1, thr, dscale, w.y);
+      o.z = gate_dp(g, part, ra4[i].z, rb4[i].z, wc4.z, dsv, idx + 2, thr, dscale, w.z);
+      o.w = gate_dp(g, part, ra4[i].w, rb4[i].w, wc4.w, dsv, idx + 3, thr, dscale, w.w);
       st4(lds + Map::lds(tid, i), o);
       if (do_sum) {
         csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;

@@ -6,6 +6,8 @@
 //           a = tanh(h.Wa^T+ba),                          s_part = sum_d a.Wc     models/model_modules.py:73-85  (ungated)
 //   K-pool  A_raw = sum(s_part)+bc ; per-group online-softmax partials (max, sum e, sum e.h)
 //   K-merge M = softmax(A_raw).h, (max, denom)        models/model_attention_mil_path.py:53-56
+#include <cstdlib>
+
 #include "mmf_gemm_core.h"
 #include "mmf_kernels.h"
 
@@ -61,37 +63,42 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 // B-operand loader: tile row j -> 32-row block jb = j/32.  Gated: blocks alternate a, b for the
 // same 32 attention dims, so a wave's (nb = 2t, 2t+1) accumulators hold the tanh- and the
 // sigmoid-branch pre-activations of the SAME (instance, d) in the SAME lane and register.
-template <int ROWS, int NT, bool GATED>
+// HALVES = false: 32-row blocks alternate (a, b) for the same 32 attention dims (2x2-wave tiles: a wave's
+//                 nb = 2t, 2t+1 accumulators are the tanh and sigmoid branch of the same (instance, d));
+// HALVES = true : rows [0, ROWS/2) are the a-branch, [ROWS/2, ROWS) the b-branch of dims d0 .. d0+ROWS/2-1
+//                 (1x8-wave tiles: waves 0-3 hold a, waves 4-7 hold b; they meet through LDS in the epilogue).
+template <int ROWS, int NT, bool GATED, bool HALVES>
 struct LoadGateW {
   using Map = KMap<ROWS, NT>;
-  const float *Wa, *Wb;
-  int H, D, d0, tid;
+  rsrc_t ra, rb;
+  int tid;
+  int which[Map::NV];          // wave-uniform (a wave-instruction covers 8 consecutive tile rows)
+  unsigned voff[Map::NV];
   float4 r[Map::NV];
-  __device__ inline void init(const float* wa, const float* wb, int H_, int D_, int d0_) {
-    Wa = wa; Wb = wb; H = H_; D = D_; d0 = d0_; tid = threadIdx.x;
-  }
-  // With NT == 256 vector slot i of the k-contiguous map is exactly 32-row block i
-  // (row = tid/8 + 32 i), so the branch (a|b) of a slot is a compile-time property of i.
-  static_assert(NT == 256 && Map::EXACT, "LoadGateW assumes 256 threads");
-  __device__ inline void load(int kt) {
-    const int w = tid >> 3, c = 4 * (tid & 7);
+  __device__ inline void init(const float* wa, const float* wb, int H, int D, int d0) {
+    tid = threadIdx.x;
+    ra = make_rsrc(wa, (unsigned)D * (unsigned)H * 4u);
+    rb = make_rsrc(GATED ? wb : wa, (unsigned)D * (unsigned)H * 4u);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int d;
-      const float* W;
-      if (GATED) { d = d0 + (i >> 1) * 32 + w; W = (i & 1) ? Wb : Wa; }
-      else       { d = d0 + i * 32 + w; W = Wa; }
-      int dc = d < D ? d : D - 1;
-      r[i] = ld4(W + (size_t)dc * H + kt * KC + c);
+      const int j = Map::row(tid, i);
+      int w, d;
+      if (!GATED) { w = 0; d = d0 + j; }
+      else if (HALVES) { w = j >= ROWS / 2 ? 1 : 0; d = d0 + j - w * (ROWS / 2); }
+      else { w = (j >> 5) & 1; d = d0 + (j >> 6) * 32 + (j & 31); }
+      which[i] = __builtin_amdgcn_readfirstlane(w);
+      voff[i] = (Map::valid(tid, i) && d < D) ? ((unsigned)d * (unsigned)H + 4u * Map::c4(tid, i)) * 4u : OOB;
     }
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = (unsigned)(kt * KC) * 4u;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(which[i] ? rb : ra, voff[i], soff);
   }
   __device__ inline void store(float* lds) const {
-    const int w = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      int d = GATED ? d0 + (i >> 1) * 32 + w : d0 + i * 32 + w;
-      st4(lds + Map::lds(tid, i), d < D ? r[i] : zero4());
-    }
+    for (int i = 0; i < Map::NV; ++i)
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
 };
 
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
 
   LoadK<T::BM, T::NT> la;
   la.init(p.h, p.H, row0, (int)p.N);
-  LoadGateW<T::BN, T::NT, GATED> lb;
+  LoadGateW<T::BN, T::NT, GATED, false> lb;
   lb.init(p.Wa, p.Wb, p.H, p.D, d0);
 
   f32x16 acc[T::MB][T::NB];
@@ -315,10 +322,52 @@ using TileNT64 = Tile<64, 64, 2, 2, true, true>;
 // rows-per-tile choice: big tiles once there is enough work to fill 256 CUs twice over
 static inline bool use_big_tiles(int64_t M, int N) { return (M / 128) * ((N + 127) / 128) >= 256; }
 
+// Wide tiles: (32*MB) x 256, ONE 8-wave workgroup per CU (wave w owns the 32-column strip w of every row).
+// Measured (profiles/r01/load_rate.txt): a CU pulls ~11.5 B/clk of streamed and ~29 B/clk of L2-hot operand
+// into LDS; two 128x128 workgroups per CU need 64 KB per 8192 MFMA cycles and stall on it.  A 224x256 tile
+// needs 60 KB per 14336 MFMA cycles (60 FLOP/B instead of 32) and, at N = 50k, gives exactly 224 tiles.
+template <int MB>
+using TileW = Tile<32 * MB, 256, 1, 8, true, true>;
+
+// row-block count that minimises rounds x MB over the 256 CUs (0.35: per-tile prologue/epilogue, in MB units)
+int pick_wide_mb(int64_t M, int ntn) {
+  static const int env = getenv("MMF_WIDE_MB") ? atoi(getenv("MMF_WIDE_MB")) : 0;   // tuning override
+  if (env > 0) return env;
+  int best = 7;
+  double bestc = 1e30;
+  const int cand[4] = {7, 6, 4, 2};   // MB = 8 needs > 256 VGPRs with double-buffered fragments (spills)
+  for (int mb : cand) {
+    int64_t tiles = ((M + 32 * mb - 1) / (32 * mb)) * ntn;
+    int64_t rounds = (tiles + 255) / 256;
+    double c = (double)rounds * (mb + 0.35);
+    if (c < bestc) { bestc = c; best = mb; }
+  }
+  return best;
+}
+bool use_wide_tiles(int64_t M, int N) {
+  static const int env = getenv("MMF_WIDE") ? atoi(getenv("MMF_WIDE")) : 1;
+  return env && N % 256 == 0 && M * (int64_t)(N / 256) >= 64 * 256;
+}
+
+template <int MB>
+static int launch_linear_wide(LinearParams p, hipStream_t st) {
+  using T = TileW<MB>;
+  p.mt_count = (int)((p.M + T::BM - 1) / T::BM); p.nt_count = p.N / 256;
+  return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+}
+
 int launch_linear(LinearParams p, hipStream_t st) {
   if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
   if (p.M <= 0) return MMF_OK;
+  if (use_wide_tiles(p.M, p.N)) {
+    switch (pick_wide_mb(p.M, p.N / 256)) {
+      case 2: return launch_linear_wide<2>(p, st);
+      case 4: return launch_linear_wide<4>(p, st);
+      case 6: return launch_linear_wide<6>(p, st);
+      default: return launch_linear_wide<7>(p, st);
+    }
+  }
   if (use_big_tiles(p.M, p.N)) {
     p.mt_count = (int)((p.M + 127) / 128); p.nt_count = (p.N + 127) / 128;
     return launch_tiled<TileNT128>("linear_nt_kernel", linear_nt_kernel<TileNT128>, p, grid_for_tiles(p.mt_count, p.nt_count), st);

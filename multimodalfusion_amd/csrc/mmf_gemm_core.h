@@ -67,6 +67,33 @@ struct MMap {   // m-contiguous image [KC][ROWS]: ROWS/4 float4 per k-row
   __device__ static inline int lds(int tid, int i) { return krow(tid, i) * ROWS + 4 * c4(tid, i); }
 };
 
+// ---- buffer loads -----------------------------------------------------------------------------
+// Every operand is read with `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen`: a 4-SGPR resource
+// (base, num_records), a per-thread byte offset computed ONCE, and a scalar offset that advances per
+// chunk.  Two reasons, both measured:
+//   * no per-chunk 64-bit VGPR address arithmetic.  With global_load, hipcc re-derived the addresses each
+//     chunk into VGPRs it believed still had loads in flight and put s_waitcnt vmcnt(0) in front of the
+//     second operand's loads, serialising them;
+//   * the hardware range check returns 0 for offsets >= num_records, which is exactly the zero-fill a
+//     ragged last tile needs (rows beyond the bag, k beyond the split) -- no clamps, no selects.
+// Limits: an operand must be < 4 GiB (checked by the launchers).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;   // a byte offset no operand reaches: reads as zero
+
+__device__ inline rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ inline float4 bld4(rsrc_t r, unsigned voff, unsigned soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  float4 f;
+  f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+  return f;
+}
+__device__ inline float bld1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
 // ---- generic loaders ----------------------------------------------------------------------
 // k-contiguous source S[row][k] (leading dimension ld); rows >= nrows read as zero.  The k range
 // may be a concatenation of `nseg` equal segments held in separate buffers (radio: the four
@@ -74,70 +101,77 @@ struct MMap {   // m-contiguous image [KC][ROWS]: ROWS/4 float4 per k-row
 template <int ROWS, int NT>
 struct LoadK {
   using Map = KMap<ROWS, NT>;
-  const float *s0, *s1, *s2, *s3;
-  int kseg, ld, row0, nrows, tid;
+  rsrc_t r0, r1, r2, r3;
+  int kseg, tid;
+  unsigned voff[Map::NV];
   float4 r[Map::NV];
-  __device__ inline void init(const float* p0, int ld_, int row0_, int nrows_) {
-    s0 = p0; s1 = s2 = s3 = nullptr; kseg = 1 << 30;
-    ld = ld_; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+  __device__ inline void set_offsets(int ld, int row0, int nrows) {
+    tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int rr = row0 + Map::row(tid, i);
+      voff[i] = (Map::valid(tid, i) && rr < nrows) ? ((unsigned)rr * (unsigned)ld + 4u * Map::c4(tid, i)) * 4u : OOB;
+    }
   }
-  __device__ inline void init_segments(const float* const* p, int nseg, int kseg_, int ld_, int row0_, int nrows_) {
-    s0 = p[0]; s1 = nseg > 1 ? p[1] : nullptr; s2 = nseg > 2 ? p[2] : nullptr; s3 = nseg > 3 ? p[3] : nullptr;
-    kseg = kseg_; ld = ld_; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+  __device__ inline void init(const float* p0, int ld, int row0, int nrows) {
+    r0 = r1 = r2 = r3 = make_rsrc(p0, (unsigned)nrows * (unsigned)ld * 4u);
+    kseg = 1 << 30;
+    set_offsets(ld, row0, nrows);
+  }
+  __device__ inline void init_segments(const float* const* p, int nseg, int kseg_, int ld, int row0, int nrows) {
+    const unsigned bytes = (unsigned)nrows * (unsigned)ld * 4u;
+    r0 = make_rsrc(p[0], bytes);
+    r1 = make_rsrc(p[nseg > 1 ? 1 : 0], bytes);
+    r2 = make_rsrc(p[nseg > 2 ? 2 : 0], bytes);
+    r3 = make_rsrc(p[nseg > 3 ? 3 : 0], bytes);
+    kseg = kseg_;
+    set_offsets(ld, row0, nrows);
   }
   __device__ inline void load(int kt) {
-    int k0 = kt * KC;
-    int sidx = k0 / kseg;
-    const float* base = (sidx == 0 ? s0 : sidx == 1 ? s1 : sidx == 2 ? s2 : s3) + (k0 - sidx * kseg);
+    const int k0 = kt * KC;
+    const int sidx = k0 / kseg;
+    const rsrc_t rs = sidx == 0 ? r0 : (sidx == 1 ? r1 : (sidx == 2 ? r2 : r3));
+    const unsigned soff = (unsigned)(k0 - sidx * kseg) * 4u;
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      // unconditional load from a clamped (always valid) address, then select: a predicated load
-      // would compile to an exec-masked branch + vmcnt(0) per element
-      int rr = row0 + Map::row(tid, i);
-      int rc = rr < nrows ? rr : nrows - 1;
-      r[i] = ld4(base + (size_t)rc * ld + 4 * Map::c4(tid, i));
-    }
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(rs, voff[i], soff);
   }
-  // the zero-select sits HERE (after the MFMAs of the previous chunk), not in load(): a select in
-  // load() makes the compiler wait for the loads before the MFMA block they are meant to overlap
   __device__ inline void store(float* lds) const {
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      bool ok = row0 + Map::row(tid, i) < nrows;
-      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), ok ? r[i] : zero4());
-    }
+    for (int i = 0; i < Map::NV; ++i)
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
 };
 
-// m-contiguous source S[k][m]; k rows outside [0, kmax) and columns >= ncols read as zero.
+// m-contiguous source S[k][m]; k rows outside [kbase, kmax) and columns >= ncols read as zero
+// (the resource ends at row kmax, so the range check does the k tail).
 template <int ROWS, int NT>
 struct LoadM {
   using Map = MMap<ROWS, NT>;
-  const float* src;
-  int ld, col0, ncols, kbase, kmax, tid, kt_loaded;
+  rsrc_t rs;
+  unsigned ldb, kbase_b;
+  int tid;
+  unsigned voff[Map::NV];
   float4 r[Map::NV];
-  __device__ inline void init(const float* s, int ld_, int col0_, int ncols_, int kbase_, int kmax_) {
-    src = s; ld = ld_; col0 = col0_; ncols = ncols_; kbase = kbase_; kmax = kmax_; tid = threadIdx.x;
-    kt_loaded = 0;
-  }
-  __device__ inline void load(int kt) {
-    kt_loaded = kt;
+  __device__ inline void init(const float* s, int ld, int col0, int ncols, int kbase, int kmax) {
+    tid = threadIdx.x;
+    rs = make_rsrc(s, (unsigned)(kmax > 0 ? kmax : 0) * (unsigned)ld * 4u);
+    ldb = (unsigned)ld * 4u;
+    kbase_b = (unsigned)kbase * ldb;
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      int k = kbase + kt * KC + Map::krow(tid, i);
       int c = col0 + 4 * Map::c4(tid, i);
-      int kc = k < kmax ? k : kmax - 1;
-      int cc = c < ncols ? c : ncols - 4;
-      r[i] = ld4(src + (size_t)kc * ld + cc);
+      voff[i] = (Map::valid(tid, i) && c < ncols) ? (unsigned)Map::krow(tid, i) * ldb + (unsigned)c * 4u : OOB;
     }
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = kbase_b + (unsigned)(kt * KC) * ldb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(rs, voff[i], soff);
   }
   __device__ inline void store(float* lds) const {
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      int k = kbase + kt_loaded * KC + Map::krow(tid, i);
-      int c = col0 + 4 * Map::c4(tid, i);
-      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), (k < kmax && c < ncols) ? r[i] : zero4());
-    }
+    for (int i = 0; i < Map::NV; ++i)
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
 };
 
@@ -189,9 +223,13 @@ __device__ inline void mfma_frags(const Frags<T>& f, f32x16 (&acc)[T::MB][T::NB]
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][j], f.b[nb][j], acc[mb][nb], 0, 0, 0);
 }
 
-template <class T>
+// `hook(q)` runs in front of the MFMA block of k-group q (q = 0..3): the main loop uses it to spread the
+// staging of the NEXT chunk through this chunk's MFMA stream (global loads in groups 0-1, LDS writes in
+// groups 2-3) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
+// address path: ~2000 cycles for a CU's 60 KB) and the LDS writes stalled every wave at once.
+template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
-                                     f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane) {
+                                     f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook) {
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + r;
   const int brow = wn * T::NB * 32 + r;
@@ -200,19 +238,18 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
 #pragma unroll
   for (int q = 0; q < KC / 8; q += 2) {
     read_frags<T>(As, Bs, q + 1, arow, brow, hh, f1);
+    hook(q);
     __builtin_amdgcn_sched_barrier(0);
     mfma_frags<T>(f0, acc);
     __builtin_amdgcn_sched_barrier(0);
     if (q + 2 < KC / 8) read_frags<T>(As, Bs, q + 2, arow, brow, hh, f0);
+    hook(q + 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_frags<T>(f1, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// ---- double-buffered main loop ---------------------------------------------------------------
-// Loader concept: load(kt) issues the global loads of chunk kt into the loader's registers,
-// store(lds) writes them (possibly transformed) into the operand's LDS image.
 // Diagnostic build only (-DMMF_STAMPS): s_memtime phase stamps of the main loop, summed per wave into a
 // per-translation-unit device array that no kernel reads (guide: "In-kernel stamps").  The shipped
 // library is built without the macro and contains no stamp.
@@ -254,17 +291,15 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     float* nxt = lds + ((kt + 1) & 1) * T::STAGE_FLOATS;
     const bool more = kt + 1 < nk;
     MMF_STAMP(t0);
-    if (more) {
-      la.load(kt + 1);
-      lb.load(kt + 1);
-    }
     MMF_STAMP(t1);
-    compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane);
+    compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int q) {
+      if (!more) return;
+      if (q == 0) la.load(kt + 1);
+      else if (q == 1) lb.load(kt + 1);
+      else if (q == 2) la.store(nxt);
+      else lb.store(nxt + T::A_FLOATS);
+    });
     MMF_STAMP(t2);
-    if (more) {
-      la.store(nxt);
-      lb.store(nxt + T::A_FLOATS);
-    }
     MMF_STAMP(t3);
     __syncthreads();
     MMF_STAMP(t4);
