@@ -177,12 +177,35 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   f32x16 acc[T::MB][T::NB];
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
   gemm_mainloop<T>(la, lb, nk, lds, acc);
-  for_each_c<T>(acc, [&](int r, int c, float v) {
-    int row = row0 + r, col = col0 + c;
-    if (row < p.N && col < p.H) {
-      size_t o = (size_t)row * p.H + col;
-      float dh = v + p.p[row] * p.dM[col];
-      p.du[o] = p.h[o] > 0.f ? dh * p.scale_h : 0.f;
+  float4 dm4[T::NB];                         // dM of this lane's columns, loaded once
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb) {
+    const int col = col0 + epilogue_col<T>(nb);
+    dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
+  }
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = col0 + c;
+    if (col >= p.H) return;
+    float4 hv[4];
+    float pi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {             // all loads first ...
+      const int row = row0 + r + 8 * t;
+      const int rc = row < p.N ? row : (int)p.N - 1;
+      hv[t] = ld4(p.h + (size_t)rc * p.H + col);
+      pi[t] = p.p[rc];
+    }
+    const float4 dm = dm4[nb];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {             // ... then the stores
+      const int row = row0 + r + 8 * t;
+      if (row >= p.N) continue;
+      float4 du;
+      du.x = hv[t].x > 0.f ? (v[t].x + pi[t] * dm.x) * p.scale_h : 0.f;
+      du.y = hv[t].y > 0.f ? (v[t].y + pi[t] * dm.y) * p.scale_h : 0.f;
+      du.z = hv[t].z > 0.f ? (v[t].z + pi[t] * dm.z) * p.scale_h : 0.f;
+      du.w = hv[t].w > 0.f ? (v[t].w + pi[t] * dm.w) * p.scale_h : 0.f;
+      st4(p.du + (size_t)row * p.H + col, du);
     }
   });
 }
@@ -202,9 +225,14 @@ __global__ __launch_bounds__(T::NT) void gemm_nn_kernel(NnParams p) {
   lb.init(p.B, p.ldb, col0, p.N, 0, p.K);
   f32x16 acc[T::MB][T::NB];
   gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
-  for_each_c<T>(acc, [&](int r, int c, float v) {
-    int row = row0 + r, col = col0 + c;
-    if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = col0 + c;
+    if (col >= p.N) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = row0 + r + 8 * t;
+      if (row < p.M) st4(p.C + (size_t)row * p.ldc + col, v[t]);
+    }
   });
 }
 
@@ -249,13 +277,19 @@ struct LoadA_M_Plain {
   }
 };
 
-template <int ROWS, int NT>
-struct LoadA_M_Gate {   // A[k = instance][m] = dP over the stacked (d pre-tanh | d pre-sigmoid) columns
-  using Map = MMap<ROWS, NT>;
-  static_assert(NT % Map::VPR == 0, "a thread must own the same columns in every vector slot");
+// A[k = instance][m] = dP.  One tile covers DT attention dims d0 .. d0+DT-1:
+//   gated  : DT = ROWS/2; image columns [0, DT) = d pre-tanh, [DT, ROWS) = d pre-sigmoid of the SAME dims, so a
+//            thread loads a, b (and ds) once and emits both halves -- half the loads and loader registers of a
+//            layout that puts the two halves in different tiles;
+//   ungated: DT = ROWS, columns = d pre-tanh.
+template <int ROWS, int NT, bool GATED>
+struct LoadA_M_Gate {
+  static constexpr int DT = GATED ? ROWS / 2 : ROWS;
+  using Map = MMap<DT, NT>;
+  static_assert(NT % Map::VPR == 0 && Map::EXACT, "a thread must own the same columns in every vector slot");
   GateBwdCtx g;
   rsrc_t ra, rb, rds;
-  int part, d0, kbase, tid, kt_loaded;
+  int d0, kbase, tid, kt_loaded;
   bool do_sum;
   uint32_t thr;
   float dscale;
@@ -263,24 +297,22 @@ struct LoadA_M_Gate {   // A[k = instance][m] = dP over the stacked (d pre-tanh 
   unsigned voff[Map::NV], voff_ds[Map::NV];
   float4 ra4[Map::NV], rb4[Map::NV], wc4;
   float dsr[Map::NV];
-  float4 csum, csum2;   // column sums of dP (bias grads) and of ds.a_d.b_d (dWc)
-  __device__ inline void init(const GateBwdCtx& g_, int col0, int kbase_, int kmax, bool do_sum_) {
-    g = g_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
-    part = col0 >= g.D ? 1 : 0;
-    d0 = col0 - part * g.D;
+  float4 csum_a, csum_b, csum2;   // column sums: d pre-tanh, d pre-sigmoid (bias grads), ds.a_d.b_d (dWc)
+  __device__ inline void init(const GateBwdCtx& g_, int d0_, int kbase_, int kmax, bool do_sum_) {
+    g = g_; d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-    csum = zero4(); csum2 = zero4();
+    csum_a = zero4(); csum_b = zero4(); csum2 = zero4();
     db = (unsigned)g.D * 4u;
     const unsigned rows = (unsigned)(kmax > 0 ? kmax : 0);
     ra = make_rsrc(g.a, rows * db);
-    rb = make_rsrc(g.gated ? g.b : g.a, rows * db);
+    rb = make_rsrc(GATED ? g.b : g.a, rows * db);
     rds = make_rsrc(g.ds, rows * 4u);
     const int c = d0 + 4 * Map::c4(tid, 0);
     wc4 = bld4(make_rsrc(g.Wc, db), c < g.D ? (unsigned)c * 4u : OOB, 0);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      bool ok = Map::valid(tid, i) && c < g.D;
+      const bool ok = c < g.D;
       voff[i] = ok ? (unsigned)Map::krow(tid, i) * db + (unsigned)c * 4u : OOB;
       voff_ds[i] = ok ? (unsigned)Map::krow(tid, i) * 4u : OOB;
     }
@@ -292,67 +324,100 @@ struct LoadA_M_Gate {   // A[k = instance][m] = dP over the stacked (d pre-tanh 
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
       ra4[i] = bld4(ra, voff[i], k0 * db);
-      rb4[i] = bld4(rb, voff[i], k0 * db);
+      if (GATED) rb4[i] = bld4(rb, voff[i], k0 * db);
       dsr[i] = bld1(rds, voff_ds[i], k0 * 4u);    // 0 beyond the split's last instance => dP = 0 there
     }
   }
   __device__ inline void store(float* lds) {
     const int c = d0 + 4 * Map::c4(tid, 0);
+    GateBwdCtx gg = g;
+    gg.gated = GATED ? 1 : 0;
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
-      if (!Map::valid(tid, i)) continue;
-      int k = kbase + kt_loaded * KC + Map::krow(tid, i);
-      uint32_t idx = (uint32_t)k * (uint32_t)g.D + (uint32_t)c;
+      const int k = kbase + kt_loaded * KC + Map::krow(tid, i);
+      const uint32_t idx = (uint32_t)k * (uint32_t)g.D + (uint32_t)c;
       const float dsv = dsr[i];
-      float4 o, w;
-      o.x = gate_dp(g, part, ra4[i].x, rb4[i].x, wc4.x, dsv, idx + 0, thr, dscale, w.x);
-      o.y = gate_dp(g, part, ra4[i].y, rb4[i].y, wc4.y, dsv, idx + 1, thr, dscale, w.y);
-      o.z = gate_dp(g, part, ra4[i].z, rb4[i].z, wc4.z, dsv, idx + 2, thr, dscale, w.z);
-      o.w = gate_dp(g, part, ra4[i].w, rb4[i].w, wc4.w, dsv, idx + 3, thr, dscale, w.w);
-      st4(lds + Map::lds(tid, i), o);
+      const float av[4] = {ra4[i].x, ra4[i].y, ra4[i].z, ra4[i].w};
+      const float bv[4] = {rb4[i].x, rb4[i].y, rb4[i].z, rb4[i].w};
+      const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
+      float oa[4], ob[4], w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oa[e] = gate_dp(gg, 0, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
+        ob[e] = GATED ? gate_dp(gg, 1, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
+      }
+      float* dst = lds + Map::krow(tid, i) * ROWS + 4 * Map::c4(tid, i);
+      st4(dst, make_float4(oa[0], oa[1], oa[2], oa[3]));
+      if (GATED) st4(dst + DT, make_float4(ob[0], ob[1], ob[2], ob[3]));
       if (do_sum) {
-        csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
-        csum2.x += dsv * w.x; csum2.y += dsv * w.y; csum2.z += dsv * w.z; csum2.w += dsv * w.w;
+        csum_a.x += oa[0]; csum_a.y += oa[1]; csum_a.z += oa[2]; csum_a.w += oa[3];
+        csum_b.x += ob[0]; csum_b.y += ob[1]; csum_b.z += ob[2]; csum_b.w += ob[3];
+        csum2.x += dsv * w[0]; csum2.y += dsv * w[1]; csum2.z += dsv * w[2]; csum2.w += dsv * w[3];
       }
     }
   }
 };
 
-// reduce a per-thread float4 column sum over the NT/VPR threads that own the same columns
-template <class T>
+// reduce a per-thread float4 column sum over the NT/(COLS/4) threads that own the same 4 of COLS columns
+template <int COLS, int NT>
 __device__ inline void colsum_reduce_store(float* lds, float4 v, float* dst, int col0, int ncols) {
-  constexpr int VPR = T::BM / 4, GROUPS = T::NT / VPR;
+  constexpr int VPR = COLS / 4, GROUPS = NT / VPR;
   const int tid = threadIdx.x;
   __syncthreads();
-  st4(lds + (tid / VPR) * T::BM + 4 * (tid % VPR), v);
+  st4(lds + (tid / VPR) * COLS + 4 * (tid % VPR), v);
   __syncthreads();
-  if (tid < T::BM) {
+  if (tid < COLS) {
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < GROUPS; ++q) s += lds[q * T::BM + tid];
+    for (int q = 0; q < GROUPS; ++q) s += lds[q * COLS + tid];
     if (col0 + tid < ncols) dst[col0 + tid] = s;
   }
 }
 
-template <class T>
-__device__ inline void tn_store(const TnProblem& q, int split, int tm, int tn, f32x16 (&acc)[T::MB][T::NB]) {
+// rowmap(tile_row) -> output row, or -1 to drop it
+template <class T, class RowMap>
+__device__ inline void tn_store(const TnProblem& q, int split, int tn, f32x16 (&acc)[T::MB][T::NB], float* lds,
+                                RowMap&& rowmap) {
   float* out = q.out + (size_t)split * q.split_stride;
-  for_each_c<T>(acc, [&](int r, int c, float v) {
-    int row = tm * T::BM + r, col = tn * T::BN + c;
-    if (row < q.M && col < q.Ncols) out[(size_t)row * q.ldc + col] = v;
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = tn * T::BN + c;
+    if (col >= q.Ncols) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rowmap(r + 8 * t);
+      if (row >= 0) st4(out + (size_t)row * q.ldc + col, v[t]);
+    }
   });
+}
+
+template <class T, bool GATED>
+__device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q, LoadM<T::BN, T::NT>& lb, int split, int tm,
+                                    int tn, int kbase, int kmax, int nk, bool do_sum, float* lds) {
+  using LA = LoadA_M_Gate<T::BM, T::NT, GATED>;
+  constexpr int DT = LA::DT;
+  const int D = p.g.D, d0 = tm * DT;
+  LA la;
+  la.init(p.g, d0, kbase, kmax, do_sum);
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, nk, lds, acc);
+  tn_store<T>(q, split, tn, acc, lds, [&](int r) {      // tile row -> row of the stacked [dWa ; dWb] slab
+    const int half = r / DT, d = d0 + r - half * DT;
+    return d < D ? half * D + d : -1;
+  });
+  if (do_sum) {
+    float* cs = q.colsum + (size_t)split * q.colsum_stride;
+    colsum_reduce_store<DT, T::NT>(lds, la.csum_a, cs, d0, D);
+    if (GATED) colsum_reduce_store<DT, T::NT>(lds, la.csum_b, cs + D, d0, D);
+    if (q.colsum2) colsum_reduce_store<DT, T::NT>(lds, la.csum2, q.colsum2 + (size_t)split * q.colsum2_stride, d0, D);
+  }
 }
 
 template <class T>
 __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   extern __shared__ __align__(16) float lds[];
-  // XCD-aware block -> (split, tile) map.  Blocks b, b+8, ... share an XCD (round-robin dispatch; speed only):
-  // every tile of one K-split is put on ONE XCD, so the operand rows of that split are fetched into that
-  // XCD's L2 once and shared by all its tiles, instead of once per tile through eight different L2s
-  // (the first version moved ~1.3 GB per launch through the fabric and ran at 55 % MFMA utilisation).
   const int b = blockIdx.x;
   int split, tg;
-  if (p.xcd_map) {
+  if (p.xcd_map) {       // every tile of one K-split on one XCD (measured: no gain -- the L2s were not the limit)
     const int xcd = b & 7, idx = b >> 3;
     split = xcd + 8 * (idx / p.total_tiles);
     tg = idx % p.total_tiles;
@@ -375,23 +440,18 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
 
   LoadM<T::BN, T::NT> lb;
   lb.init(q.B, q.ldb, tn * T::BN, q.Ncols, kbase, kmax);
-  f32x16 acc[T::MB][T::NB];
   if (q.kind == TN_A_PLAIN) {
     LoadA_M_Plain<T::BM, T::NT> la;
     la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
+    f32x16 acc[T::MB][T::NB];
     gemm_mainloop<T>(la, lb, nk, lds, acc);
-    tn_store<T>(q, split, tm, tn, acc);
-    if (do_sum) colsum_reduce_store<T>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+    tn_store<T>(q, split, tn, acc, lds, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
+    if (do_sum)
+      colsum_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+  } else if (p.g.gated) {
+    tn_gate_tile<T, true>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
   } else {
-    LoadA_M_Gate<T::BM, T::NT> la;
-    la.init(p.g, tm * T::BM, kbase, kmax, do_sum);
-    gemm_mainloop<T>(la, lb, nk, lds, acc);
-    tn_store<T>(q, split, tm, tn, acc);
-    if (do_sum) {
-      colsum_reduce_store<T>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
-      if (la.part == 0 && q.colsum2)
-        colsum_reduce_store<T>(lds, la.csum2, q.colsum2 + (size_t)split * q.colsum2_stride, la.d0, p.g.D);
-    }
+    tn_gate_tile<T, false>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
   }
 }
 
@@ -490,16 +550,38 @@ int launch_nn(NnParams p, hipStream_t st) {
   return launch_tiled<T>("gemm_nn_kernel", gemm_nn_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
-int launch_tn(TnParams p, hipStream_t st) {
-  using T = Tile<128, 128, 2, 2, false, false>;
+// Tile / split plan of the TN GEMM.  256x256 tiles (8 waves, one workgroup per CU): 65 FLOP per operand byte
+// instead of 32, which is what the per-CU load rate needs (profiles/r01/load_rate.txt); the price is twice the
+// splits (slab traffic) for the same number of workgroups, so it is used only for long K.
+int tn_tile_dim(int64_t K, int D_gate) {
+  static const int env = getenv("MMF_TN_WIDE") ? atoi(getenv("MMF_TN_WIDE")) : 1;
+  if (!env || K < 8192) return 128;
+  (void)D_gate;
+  return 256;
+}
+int tn_splits(int64_t K, int total_tiles, int tile) {
+  static const int env_splits = getenv("MMF_TN_SPLITS") ? atoi(getenv("MMF_TN_SPLITS")) : 0;   // tuning override
+  int splits = (tile == 256 ? 256 : 512) / (total_tiles > 0 ? total_tiles : 1);
+  if (env_splits > 0) splits = env_splits;
+  const int64_t max_splits = (K + 127) / 128;
+  if (splits > max_splits) splits = (int)max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+template <class T>
+static int launch_tn_t(TnParams p, hipStream_t st) {
   if (p.k_per_split % KC != 0 || p.splits < 1) return MMF_ERR_ARG;
   int blocks = 0;
   for (int i = 0; i < p.nprob; ++i) {
     TnProblem& q = p.prob[i];
     if (q.Ncols % 4 != 0 || q.ldb % 4 != 0 || q.M % 4 != 0) return MMF_ERR_SHAPE;
     if (q.kind == TN_A_PLAIN && q.lda % 4 != 0) return MMF_ERR_SHAPE;
-    if (q.kind == TN_A_GATE && (p.g.D % T::BM != 0)) return MMF_ERR_SHAPE;   // a tile never straddles the a|b halves
-    q.tiles_m = (q.M + T::BM - 1) / T::BM;
+    if (q.kind == TN_A_GATE) {
+      const int dt = p.g.gated ? T::BM / 2 : T::BM;      // attention dims per tile (both halves together when gated)
+      q.tiles_m = (p.g.D + dt - 1) / dt;
+    } else {
+      q.tiles_m = (q.M + T::BM - 1) / T::BM;
+    }
     q.tiles_n = (q.Ncols + T::BN - 1) / T::BN;
     q.block_begin = blocks;          // first global tile index of this problem
     blocks += q.tiles_m * q.tiles_n;
@@ -510,6 +592,11 @@ int launch_tn(TnParams p, hipStream_t st) {
   p.xcd_map = env_xcd >= 0 ? env_xcd : 0;
   const int grid = (p.xcd_map ? 8 * ((p.splits + 7) / 8) : p.splits) * blocks;
   return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
+}
+
+int launch_tn(TnParams p, hipStream_t st) {
+  if (p.tile == 256) return launch_tn_t<Tile<256, 256, 2, 4, false, false, 2>>(p, st);
+  return launch_tn_t<Tile<128, 128, 2, 2, false, false, 2>>(p, st);
 }
 
 int launch_reduce(ReduceParams p, hipStream_t st) {

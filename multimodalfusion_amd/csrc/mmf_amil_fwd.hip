@@ -42,19 +42,42 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   lb.init(p.w, p.K, col0, p.N);
 
   f32x16 acc[T::MB][T::NB];
+  MMF_STAMP(k0);
   gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+  MMF_STAMP(k1);
 
   const uint32_t thr = drop_threshold(p.drop_p);
   const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  for_each_c<T>(acc, [&](int r, int c, float v) {
-    int row = row0 + r, col = col0 + c;
-    if (row < p.M && col < p.N) {
-      float y = v + (p.bias ? p.bias[col] : 0.f);
-      y = apply_act(y, p.act);
-      if (p.drop_p > 0.f) y = keep(p.drop_key, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, thr) ? y * scale : 0.f;
-      p.y[(size_t)row * p.N + col] = y;
+  float4 bias4[T::NB];                       // per column strip, loaded once, before any store
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb) {
+    const int col = col0 + epilogue_col<T>(nb);
+    bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
+  }
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = col0 + c;
+    if (col >= p.N) return;                  // N % 4 == 0: a float4 never straddles the edge
+    const float4 b4 = bias4[nb];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = row0 + r + 8 * t;
+      if (row >= p.M) continue;
+      float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
+      const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = apply_act(y[e], p.act);
+        if (p.drop_p > 0.f) y[e] = keep(p.drop_key, idx + e, thr) ? y[e] * scale : 0.f;
+      }
+      st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
     }
   });
+#ifdef MMF_STAMPS
+  MMF_STAMP(k2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_stamps[5], k1 - k0); atomicAdd(&g_stamps[6], k2 - k1); atomicAdd(&g_stamps[7], 1ull);
+  }
+#endif
 }
 
 // =============================================================================================
@@ -118,66 +141,69 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   f32x16 acc[T::MB][T::NB];
   gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
 
-  // ---- epilogue: activations, stores, per-row partial score -----------------------------
+  // ---- epilogue (row-major, float4): activations, stores of a / b, per-row partial score ----------------
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
-  const int r = lane & 31, hh = lane >> 5;
+  const int rr = lane >> 3, c4 = lane & 7;
   const uint32_t thr = drop_threshold(p.drop_p);
   const bool drop = p.drop_p > 0.f;
   const float dscale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  float* sred = lds;   // [WN][BM] row partials; the main loop's last barrier has retired all LDS reads
+  float* blk = lds + wave * (32 * EPI_STRIDE);
+  float* sred = lds + (T::NT / 64) * (32 * EPI_STRIDE);   // [WN][BM] row partials, behind the transpose scratch
 
+  constexpr int NPAIR = GATED ? T::NB / 2 : T::NB;
+  float4 ba_r[NPAIR], bb_r[NPAIR], wc_r[NPAIR];   // per column strip, loaded once, before any store
+#pragma unroll
+  for (int t = 0; t < NPAIR; ++t) {
+    const int d = d0 + (wn * NPAIR + t) * 32 + 4 * c4;
+    const bool dok = d < p.D;
+    ba_r[t] = dok ? ld4(p.ba + d) : zero4();
+    bb_r[t] = (GATED && dok) ? ld4(p.bb + d) : zero4();
+    wc_r[t] = dok ? ld4(p.Wc + d) : zero4();
+  }
 #pragma unroll
   for (int mb = 0; mb < T::MB; ++mb) {
-    float rowsum[16];
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};     // rows rr + 8t of this 32-row block, this lane's columns
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rowsum[i] = 0.f;
-    if constexpr (GATED) {
+    for (int t = 0; t < NPAIR; ++t) {
+      const int d = d0 + (wn * NPAIR + t) * 32 + 4 * c4;
+      const bool dok = d < p.D;
+      float4 va[4], vb[4];
+      transpose_block(acc[mb][GATED ? 2 * t : t], blk, lane, va);
+      if constexpr (GATED) transpose_block(acc[mb][2 * t + 1], blk, lane, vb);
+      const float4 ba4 = ba_r[t], bb4 = bb_r[t], wc4 = wc_r[t];
 #pragma unroll
-      for (int t = 0; t < T::NB / 2; ++t) {
-        const int d = d0 + (wn * (T::NB / 2) + t) * 32 + r;
-        const bool dok = d < p.D;
-        const float bav = dok ? p.ba[d] : 0.f, bbv = dok ? p.bb[d] : 0.f, wc = dok ? p.Wc[d] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = row0 + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          float av = fast_tanh(acc[mb][2 * t][i] + bav);
-          float bv = fast_sigmoid(acc[mb][2 * t + 1][i] + bbv);
-          if (row < p.N && dok) {
-            size_t o = (size_t)row * p.D + d;
-            p.a[o] = av;
-            p.b[o] = bv;
-            if (drop) {
-              uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
-              av = keep(p.key_a, idx, thr) ? av * dscale : 0.f;
-              bv = keep(p.key_b, idx, thr) ? bv * dscale : 0.f;
-            }
-            rowsum[i] += av * bv * wc;
-          }
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + (wm * T::MB + mb) * 32 + rr + 8 * q;
+        float av[4] = {fast_tanh(va[q].x + ba4.x), fast_tanh(va[q].y + ba4.y), fast_tanh(va[q].z + ba4.z), fast_tanh(va[q].w + ba4.w)};
+        float bv[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (GATED) {
+          bv[0] = fast_sigmoid(vb[q].x + bb4.x); bv[1] = fast_sigmoid(vb[q].y + bb4.y);
+          bv[2] = fast_sigmoid(vb[q].z + bb4.z); bv[3] = fast_sigmoid(vb[q].w + bb4.w);
         }
-      }
-    } else {
+        if (row < p.N && dok) {
+          const size_t o = (size_t)row * p.D + d;
+          st4(p.a + o, make_float4(av[0], av[1], av[2], av[3]));
+          if constexpr (GATED) st4(p.b + o, make_float4(bv[0], bv[1], bv[2], bv[3]));
+          const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
+          const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
 #pragma unroll
-      for (int nb = 0; nb < T::NB; ++nb) {
-        const int d = d0 + (wn * T::NB + nb) * 32 + r;
-        const bool dok = d < p.D;
-        const float bav = dok ? p.ba[d] : 0.f, wc = dok ? p.Wc[d] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = row0 + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          float av = fast_tanh(acc[mb][nb][i] + bav);
-          if (row < p.N && dok) {
-            p.a[(size_t)row * p.D + d] = av;
-            if (drop) av = keep(p.key_a, (uint32_t)row * (uint32_t)p.D + (uint32_t)d, thr) ? av * dscale : 0.f;
-            rowsum[i] += av * wc;
+          for (int e = 0; e < 4; ++e) {
+            float ad = av[e], bd = bv[e];
+            if (drop) {
+              ad = keep(p.key_a, idx + e, thr) ? ad * dscale : 0.f;
+              if constexpr (GATED) bd = keep(p.key_b, idx + e, thr) ? bd * dscale : 0.f;
+            }
+            rowsum[q] += ad * bd * wc[e];
           }
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float s = half_sum(rowsum[i]);
-      if (r == 0) sred[wn * T::BM + (wm * T::MB + mb) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] = s;
+    for (int q = 0; q < 4; ++q) {       // the 8 lanes that share a row hold 4 columns each
+      float s = rowsum[q];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (c4 == 0) sred[wn * T::BM + (wm * T::MB + mb) * 32 + rr + 8 * q] = s;
     }
   }
   __syncthreads();

@@ -57,7 +57,7 @@ constexpr int PREP_GROUPS = 512;
 struct AmilWs {
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
-  int parts, groups, splits, k_per_split, mstk;
+  int parts, groups, splits, k_per_split, mstk, tile;
   size_t bytes;
 };
 
@@ -73,13 +73,10 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated) {
   w.parts = gate_parts(D, gated, N);
   w.groups = pool_groups(N);
   w.mstk = gated ? 2 * D : D;
-  const int tiles = ((H + 127) / 128) * ((L + 127) / 128) + ((w.mstk + 127) / 128) * ((H + 127) / 128);
-  int splits = 512 / tiles;
-  static const int env_splits = getenv("MMF_TN_SPLITS") ? atoi(getenv("MMF_TN_SPLITS")) : 0;   // tuning override
-  if (env_splits > 0) splits = env_splits;
-  const int64_t max_splits = (N + 127) / 128;
-  if (splits > max_splits) splits = (int)max_splits;
-  if (splits < 1) splits = 1;
+  const int td = tn_tile_dim(N, D);
+  const int tiles = ((H + td - 1) / td) * ((L + td - 1) / td) + ((w.mstk + td - 1) / td) * ((H + td - 1) / td);
+  int splits = tn_splits(N, tiles, td);
+  w.tile = td;
   w.splits = splits;
   int64_t kps = (N + splits - 1) / splits;
   w.k_per_split = (int)((kps + KC - 1) / KC * KC);
@@ -206,7 +203,7 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   }
 
   TnParams tp{};
-  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc;
+  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc; tp.tile = w.tile;
   TnProblem& q1 = tp.prob[0];   // dW1[H x L] = du^T . x ; db1 = colsum(du)
   q1.kind = TN_A_PLAIN; q1.A = w.du; q1.lda = d->H; q1.M = d->H;
   q1.B = x; q1.ldb = d->L; q1.Ncols = d->L;
@@ -255,11 +252,9 @@ int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, i
 }
 
 static int linear_bwd_splits(int64_t M, int N, int K) {
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int splits = 512 / tiles;
-  const int64_t max_splits = (M + 127) / 128;
-  if (splits > max_splits) splits = (int)max_splits;
-  return splits < 1 ? 1 : splits;
+  const int td = tn_tile_dim(M, 0);
+  const int tiles = ((N + td - 1) / td) * ((K + td - 1) / td);
+  return tn_splits(M, tiles, td);
 }
 
 size_t mmf_linear_backward_workspace_bytes(int64_t M, int32_t N, int32_t K) {
@@ -282,7 +277,7 @@ int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nse
   float* cs = splits > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)splits * N * K * 4, 256)) : db;
 
   TnParams tp{};
-  tp.nprob = nseg; tp.K = M; tp.splits = splits;
+  tp.nprob = nseg; tp.K = M; tp.splits = splits; tp.tile = tn_tile_dim(M, 0);
   int64_t kps = (M + splits - 1) / splits;
   tp.k_per_split = (int)((kps + KC - 1) / KC * KC);
   for (int i = 0; i < nseg; ++i) {

@@ -29,9 +29,12 @@ namespace mmf {
 constexpr int KC = 32;         // k-chunk staged per pipeline step
 constexpr int KSTR = KC + 4;   // padded LDS row stride (floats) of a k-contiguous image
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_>
+// G = k-pairs per fragment group (one MFMA consumes one k-pair).  4 matches a ds_read_b128 of a k-contiguous
+// image; all-m-contiguous tiles may use 2, which halves the (double-buffered) fragment registers.
+template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_, int G_ = 4>
 struct Tile {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, G = G_;
+  static_assert(G_ == 4 || (G_ == 2 && !A_KCONTIG_ && !B_KCONTIG_), "G = 2 only for all-m-contiguous tiles");
   static constexpr bool A_KCONTIG = A_KCONTIG_, B_KCONTIG = B_KCONTIG_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
@@ -183,31 +186,33 @@ struct LoadM {
 // kernels to 2 waves per SIMD.
 template <class T>
 struct Frags {
-  float a[T::MB][4];
-  float b[T::NB][4];
+  float a[T::MB][T::G];
+  float b[T::NB][T::G];
 };
 
+// fragments of group g: k-values 2*G*g + G*hh + j  (j < G) for lane-half hh
 template <class T>
-__device__ inline void read_frags(const float* __restrict__ As, const float* __restrict__ Bs, int q,
+__device__ inline void read_frags(const float* __restrict__ As, const float* __restrict__ Bs, int g,
                                   int arow, int brow, int hh, Frags<T>& f) {
+  constexpr int G = T::G;
 #pragma unroll
   for (int mb = 0; mb < T::MB; ++mb) {
     if constexpr (T::A_KCONTIG) {
-      float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * q + 4 * hh);
+      float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * g + 4 * hh);
       f.a[mb][0] = t.x; f.a[mb][1] = t.y; f.a[mb][2] = t.z; f.a[mb][3] = t.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.a[mb][j] = As[(8 * q + 4 * hh + j) * T::BM + arow + mb * 32];
+      for (int j = 0; j < G; ++j) f.a[mb][j] = As[(2 * G * g + G * hh + j) * T::BM + arow + mb * 32];
     }
   }
 #pragma unroll
   for (int nb = 0; nb < T::NB; ++nb) {
     if constexpr (T::B_KCONTIG) {
-      float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * q + 4 * hh);
+      float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * g + 4 * hh);
       f.b[nb][0] = t.x; f.b[nb][1] = t.y; f.b[nb][2] = t.z; f.b[nb][3] = t.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) f.b[nb][j] = Bs[(8 * q + 4 * hh + j) * T::BN + brow + nb * 32];
+      for (int j = 0; j < G; ++j) f.b[nb][j] = Bs[(2 * G * g + G * hh + j) * T::BN + brow + nb * 32];
     }
   }
 }
@@ -215,7 +220,7 @@ __device__ inline void read_frags(const float* __restrict__ As, const float* __r
 template <class T>
 __device__ inline void mfma_frags(const Frags<T>& f, f32x16 (&acc)[T::MB][T::NB]) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < T::G; ++j)
 #pragma unroll
     for (int mb = 0; mb < T::MB; ++mb)
 #pragma unroll
@@ -223,9 +228,9 @@ __device__ inline void mfma_frags(const Frags<T>& f, f32x16 (&acc)[T::MB][T::NB]
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][j], f.b[nb][j], acc[mb][nb], 0, 0, 0);
 }
 
-// `hook(q)` runs in front of the MFMA block of k-group q (q = 0..3): the main loop uses it to spread the
-// staging of the NEXT chunk through this chunk's MFMA stream (global loads in groups 0-1, LDS writes in
-// groups 2-3) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
+// `hook(q)` (q = 0..3) runs in front of the MFMA block that opens quarter q of the chunk: the main loop uses it
+// to spread the staging of the NEXT chunk through this chunk's MFMA stream (global loads in quarters 0-1, LDS
+// writes in quarters 2-3) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
 // address path: ~2000 cycles for a CU's 60 KB) and the LDS writes stalled every wave at once.
 template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
@@ -233,17 +238,19 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + r;
   const int brow = wn * T::NB * 32 + r;
+  constexpr int NG = KC / (2 * T::G);       // fragment groups per chunk: 4 (G = 4) or 8 (G = 2)
+  constexpr int PER_Q = NG / 4;
   Frags<T> f0, f1;
   read_frags<T>(As, Bs, 0, arow, brow, hh, f0);
 #pragma unroll
-  for (int q = 0; q < KC / 8; q += 2) {
-    read_frags<T>(As, Bs, q + 1, arow, brow, hh, f1);
-    hook(q);
+  for (int g = 0; g < NG; g += 2) {
+    read_frags<T>(As, Bs, g + 1, arow, brow, hh, f1);
+    if (g % PER_Q == 0) hook(g / PER_Q);
     __builtin_amdgcn_sched_barrier(0);
     mfma_frags<T>(f0, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if (q + 2 < KC / 8) read_frags<T>(As, Bs, q + 2, arow, brow, hh, f0);
-    hook(q + 1);
+    if (g + 2 < NG) read_frags<T>(As, Bs, g + 2, arow, brow, hh, f0);
+    if ((g + 1) % PER_Q == 0) hook((g + 1) / PER_Q);
     __builtin_amdgcn_sched_barrier(0);
     mfma_frags<T>(f1, acc);
     __builtin_amdgcn_sched_barrier(0);
@@ -333,6 +340,61 @@ __device__ inline void for_each_c(f32x16 (&acc)[T::MB][T::NB], F&& f) {
         f(row, col, acc[mb][nb][i]);
       }
 }
+
+// Row-major epilogue.  The MFMA accumulator layout gives a lane ONE column and 16 rows per 32x32 block, so a
+// direct store is 16 scalar dword stores per block and lane -- store-issue bound (measured: the epilogue of the
+// 224x256 tile took half as long as its 32-chunk main loop).  Here every wave transposes one block at a time
+// through a private 32x36-float LDS scratch and hands the functor float4s that are 4 CONSECUTIVE COLUMNS of one
+// row: f(row_in_tile, col_in_tile, float4) is called 4 times per block and lane, and a functor's
+// global_store_dwordx4 covers 8 rows x 128 contiguous bytes per wave-instruction.
+// Call only after the main loop (its last barrier has retired every LDS read); needs NT/64 * 4608 bytes of LDS.
+constexpr int EPI_STRIDE = 36;
+// f(mb, nb, row_in_tile, col_in_tile, v[4]): v[t] is row (row_in_tile + 8 t), columns col_in_tile .. +3.
+// mb / nb are compile-time after unrolling, so a functor can index register arrays it preloaded per column
+// strip (bias, ...).  Functors must issue ALL their global loads before their first store: loads and stores share
+// the in-order vmcnt counter, so a load behind a store waits for that store to drain (this alone made the
+// first row-major epilogue as slow as the scalar one).
+template <class T, class F>
+__device__ inline void epilogue_rows(f32x16 (&acc)[T::MB][T::NB], float* lds, F&& f) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int r = lane & 31, hh = lane >> 5;
+  float* blk = lds + wave * (32 * EPI_STRIDE);
+  const int rr = lane >> 3, c4 = lane & 7;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) blk[((i & 3) + 8 * (i >> 2) + 4 * hh) * EPI_STRIDE + r] = acc[mb][nb][i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, in-order LDS queue: writes land before the reads
+      float4 v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = ld4(blk + (rr + 8 * t) * EPI_STRIDE + 4 * c4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the scratch
+      f(mb, nb, (wm * T::MB + mb) * 32 + rr, (wn * T::NB + nb) * 32 + 4 * c4, v);
+    }
+}
+// column (within the tile) of this lane's float4 in block-column nb of its wave: for preloading per-column data
+template <class T>
+__device__ inline int epilogue_col(int nb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return ((wave % T::WN) * T::NB + nb) * 32 + 4 * (lane & 7);
+}
+
+// one 32x32 accumulator block -> 4 float4 per lane (row rr + 8t, columns 4*c4 .. 4*c4+3), via the wave's scratch
+__device__ inline void transpose_block(const f32x16& a, float* blk, int lane, float4 (&out)[4]) {
+  const int r = lane & 31, hh = lane >> 5, rr = lane >> 3, c4 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) blk[((i & 3) + 8 * (i >> 2) + 4 * hh) * EPI_STRIDE + r] = a[i];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) out[t] = ld4(blk + (rr + 8 * t) * EPI_STRIDE + 4 * c4);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <class T>
+constexpr int epilogue_lds_bytes() { return (T::NT / 64) * 32 * EPI_STRIDE * 4; }
 
 // XCD-aware block -> (m-tile, n-tile) map.  Blocks b and b+8 land on the same XCD (round-robin
 // dispatch; speed only, never correctness), so the n-tiles of one m-tile are put 8 apart: they

@@ -102,6 +102,7 @@ struct TnParams {
   int splits, k_per_split; // k_per_split is a multiple of KC
   int total_tiles;         // tiles over all problems (set by launch_tn)
   int xcd_map;             // 1: all tiles of a split on one XCD
+  int tile;                // 128 or 256 (set by the caller from tn_tile_dim)
   GateBwdCtx g;
 };
 
@@ -125,6 +126,9 @@ int launch_pool(PoolParams p, hipStream_t st);
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
 int launch_tn(TnParams p, hipStream_t st);
+// split-K plan shared by the workspace carving and the launcher
+int tn_tile_dim(int64_t K, int D_gate);                    // 256: one 8-wave 256x256 workgroup per CU; else 128
+int tn_splits(int64_t K, int total_tiles, int tile);
 int launch_nn(NnParams p, hipStream_t st);
 int launch_reduce(ReduceParams p, hipStream_t st);
 int set_dyn_lds(const void* kern, int bytes);
