@@ -522,9 +522,24 @@ int launch_bwd_prep(BwdPrepParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+template <int MB>
+static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
+  using T = Tile<32 * MB, 256, 1, 8, true, false>;
+  p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
+  return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+}
+
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
+  if (use_wide_tiles(p.N, p.H)) {
+    switch (pick_wide_mb(p.N, p.H / 256)) {
+      case 2: return launch_bwd_dh_wide<2>(p, st);
+      case 4: return launch_bwd_dh_wide<4>(p, st);
+      case 6: return launch_bwd_dh_wide<6>(p, st);
+      default: return launch_bwd_dh_wide<7>(p, st);
+    }
+  }
   const int ntn = (p.H + 127) / 128;
   if ((p.N / 128) * ntn >= 256) {
     using T = Tile<128, 128, 2, 2, true, false>;

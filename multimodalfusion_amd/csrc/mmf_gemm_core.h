@@ -184,48 +184,52 @@ struct LoadM {
 // itself hipcc emitted read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, exposing the LDS latency every 256
 // cycles: 55 % MFMA utilisation on the TN kernel.)  Registers are free here: LDS already limits the
 // kernels to 2 waves per SIMD.
+// Fragment pipeline.  A chunk is a sequence of STEPS = (fragment group g) x (row-block part): tall tiles (MB > 4)
+// are cut in two row-block parts so that only half of the A fragments are live at a time (the 224-row tiles
+// would otherwise need 2 x 28 registers for double-buffered A fragments alone).  The fragments of step s+1 are
+// read from LDS while the MFMAs of step s issue, so an LDS read has >= 12 MFMAs (768 cycles) to land.
 template <class T>
-struct Frags {
-  float a[T::MB][T::G];
-  float b[T::NB][T::G];
-};
+struct FragA { float v[T::MB > 4 ? (T::MB + 1) / 2 : T::MB][T::G]; };
+template <class T>
+struct FragB { float v[T::NB][T::G]; };
 
-// fragments of group g: k-values 2*G*g + G*hh + j  (j < G) for lane-half hh
 template <class T>
-__device__ inline void read_frags(const float* __restrict__ As, const float* __restrict__ Bs, int g,
-                                  int arow, int brow, int hh, Frags<T>& f) {
+__device__ inline void read_a(const float* __restrict__ As, int g, int lo, int hi, int arow, int hh, FragA<T>& f) {
   constexpr int G = T::G;
 #pragma unroll
-  for (int mb = 0; mb < T::MB; ++mb) {
+  for (int mb = lo; mb < hi; ++mb) {
     if constexpr (T::A_KCONTIG) {
       float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * g + 4 * hh);
-      f.a[mb][0] = t.x; f.a[mb][1] = t.y; f.a[mb][2] = t.z; f.a[mb][3] = t.w;
+      f.v[mb - lo][0] = t.x; f.v[mb - lo][1] = t.y; f.v[mb - lo][2] = t.z; f.v[mb - lo][3] = t.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < G; ++j) f.a[mb][j] = As[(2 * G * g + G * hh + j) * T::BM + arow + mb * 32];
+      for (int j = 0; j < G; ++j) f.v[mb - lo][j] = As[(2 * G * g + G * hh + j) * T::BM + arow + mb * 32];
     }
   }
+}
+template <class T>
+__device__ inline void read_b(const float* __restrict__ Bs, int g, int brow, int hh, FragB<T>& f) {
+  constexpr int G = T::G;
 #pragma unroll
   for (int nb = 0; nb < T::NB; ++nb) {
     if constexpr (T::B_KCONTIG) {
       float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * g + 4 * hh);
-      f.b[nb][0] = t.x; f.b[nb][1] = t.y; f.b[nb][2] = t.z; f.b[nb][3] = t.w;
+      f.v[nb][0] = t.x; f.v[nb][1] = t.y; f.v[nb][2] = t.z; f.v[nb][3] = t.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < G; ++j) f.b[nb][j] = Bs[(2 * G * g + G * hh + j) * T::BN + brow + nb * 32];
+      for (int j = 0; j < G; ++j) f.v[nb][j] = Bs[(2 * G * g + G * hh + j) * T::BN + brow + nb * 32];
     }
   }
 }
-
 template <class T>
-__device__ inline void mfma_frags(const Frags<T>& f, f32x16 (&acc)[T::MB][T::NB]) {
+__device__ inline void mfma_part(const FragA<T>& fa, const FragB<T>& fb, int lo, int hi, f32x16 (&acc)[T::MB][T::NB]) {
 #pragma unroll
   for (int j = 0; j < T::G; ++j)
 #pragma unroll
-    for (int mb = 0; mb < T::MB; ++mb)
+    for (int mb = lo; mb < hi; ++mb)
 #pragma unroll
       for (int nb = 0; nb < T::NB; ++nb)
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mb][j], f.b[nb][j], acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[mb - lo][j], fb.v[nb][j], acc[mb][nb], 0, 0, 0);
 }
 
 // `hook(q)` (q = 0..3) runs in front of the MFMA block that opens quarter q of the chunk: the main loop uses it
@@ -238,21 +242,27 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + r;
   const int brow = wn * T::NB * 32 + r;
-  constexpr int NG = KC / (2 * T::G);       // fragment groups per chunk: 4 (G = 4) or 8 (G = 2)
-  constexpr int PER_Q = NG / 4;
-  Frags<T> f0, f1;
-  read_frags<T>(As, Bs, 0, arow, brow, hh, f0);
+  constexpr int NG = KC / (2 * T::G);            // fragment groups per chunk: 4 (G = 4) or 8 (G = 2)
+  constexpr int NP = T::MB > 4 ? 2 : 1;          // row-block parts
+  constexpr int MBH = T::MB > 4 ? (T::MB + 1) / 2 : T::MB;
+  constexpr int NS = NG * NP;                    // steps per chunk
+  constexpr int PER_Q = NS / 4;
+  FragA<T> fa[2];
+  FragB<T> fb[2];
+  read_b<T>(Bs, 0, brow, hh, fb[0]);
+  read_a<T>(As, 0, 0, MBH, arow, hh, fa[0]);
 #pragma unroll
-  for (int g = 0; g < NG; g += 2) {
-    read_frags<T>(As, Bs, g + 1, arow, brow, hh, f1);
-    if (g % PER_Q == 0) hook(g / PER_Q);
+  for (int s = 0; s < NS; ++s) {
+    const int g = s / NP, part = s % NP;
+    const int lo = part == 0 ? 0 : MBH, hi = part == 0 ? MBH : T::MB;
+    if (s + 1 < NS) {                            // prefetch the fragments of step s + 1
+      const int g1 = (s + 1) / NP, part1 = (s + 1) % NP;
+      if (part1 == 0) read_b<T>(Bs, g1, brow, hh, fb[g1 & 1]);
+      read_a<T>(As, g1, part1 == 0 ? 0 : MBH, part1 == 0 ? MBH : T::MB, arow, hh, fa[(s + 1) & 1]);
+    }
+    if (s % PER_Q == 0) hook(s / PER_Q);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_frags<T>(f0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < NG) read_frags<T>(As, Bs, g + 2, arow, brow, hh, f0);
-    if ((g + 1) % PER_Q == 0) hook((g + 1) / PER_Q);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_frags<T>(f1, acc);
+    mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -126,6 +126,9 @@ int launch_pool(PoolParams p, hipStream_t st);
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
 int launch_tn(TnParams p, hipStream_t st);
+// wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
+int pick_wide_mb(int64_t M, int ntn);
+bool use_wide_tiles(int64_t M, int N);
 // split-K plan shared by the workspace carving and the launcher
 int tn_tile_dim(int64_t K, int D_gate);                    // 256: one 8-wave 256x256 workgroup per CU; else 128
 int tn_splits(int64_t K, int total_tiles, int tile);
