@@ -131,12 +131,11 @@ def cpu_baseline(N, n_bags):
     import torch.nn.functional as F
     from oracle import inputs as gen
     from oracle import torch_port as tp
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     sd = tp.to_torch(gen.path_state_dict(seed=1, gated=True, size="small", n_classes=4), torch.float32)
     x = torch.as_tensor(gen.bag(1234, N))
     Y, c = torch.tensor([1]), torch.tensor([0.0])
@@ -148,15 +147,27 @@ def cpu_baseline(N, n_bags):
         loss = tp.nll_loss(hz, S, Y, c, alpha=0.0)
         loss.backward()
 
-    for _ in range(2):
+    # the box shows every host core but a 1-GPU job owns a share of them: probe a few intra-op thread counts
+    # (1 warm + 1 timed bag each) and time the sample at the fastest, so the baseline is the CPU's best case
+    best_t, best_dt = 1, float("inf")
+    for t in sorted({min(avail, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(t)
         one()
+        t0 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t0
+        if dt < best_dt:
+            best_t, best_dt = t, dt
+    torch.set_num_threads(best_t)
+    one()
     t0 = time.perf_counter()
     for _ in range(n_bags):
         one()
     dt = time.perf_counter() - t0
-    return dict(value=n_bags / dt, unit="bags/s", cores=cores, kind="port",
-                sample=f"{n_bags} bags of {N}x1024 fwd+nll_surv+bwd after 2 warm-up, fp32, train mode "
-                       f"(1 dropout mask), torch {torch.__version__} CPU, {cores} threads")
+    return dict(value=n_bags / dt, unit="bags/s", cores=best_t, kind="port",
+                sample=f"{n_bags} bags of {N}x1024 fwd+nll_surv+bwd after warm-up, fp32, train mode "
+                       f"(1 dropout mask), torch {torch.__version__} CPU, {best_t} intra-op threads "
+                       f"(fastest of 8/16/32/64 on a host showing {avail} cores)")
 
 
 def main():
@@ -221,8 +232,15 @@ def main():
         if dom in kflops:
             t_us = prof[dom]["avg_us"]
             ach = kflops[dom] / (t_us * 1e-6) / 1e12
+            traffic = None     # HBM bytes per launch from the committed PMC passes (same workload only)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if tj.get("instances") == N and dom in tj["kernels"]:
+                    traffic = tj["kernels"][dom]["bytes"]
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
         tot = flops_per_bag(N)
         out["whole_step"] = {"tflops": tot / (ms_per_step * 1e-3) / 1e12,

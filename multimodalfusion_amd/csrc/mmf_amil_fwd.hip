@@ -42,9 +42,9 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   lb.init(p.w, p.K, col0, p.N);
 
   f32x16 acc[T::MB][T::NB];
-  MMF_STAMP(k0);
+  MMF_KSTAMP(k0);
   gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
-  MMF_STAMP(k1);
+  MMF_KSTAMP(k1);
 
   const uint32_t thr = drop_threshold(p.drop_p);
   const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
     }
   });
 #ifdef MMF_STAMPS
-  MMF_STAMP(k2);
+  MMF_KSTAMP(k2);
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&g_stamps[5], k1 - k0); atomicAdd(&g_stamps[6], k2 - k1); atomicAdd(&g_stamps[7], 1ull);
   }

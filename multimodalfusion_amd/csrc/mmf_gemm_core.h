@@ -279,9 +279,15 @@ __device__ inline unsigned long long stamp_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+#ifdef MMF_STAMPS_LIGHT        /* kernel-level stamps only: nothing inside the main loop */
+#define MMF_STAMP(var)
+#else
 #define MMF_STAMP(var) unsigned long long var = stamp_now()
+#endif
+#define MMF_KSTAMP(var) unsigned long long var = stamp_now()
 #else
 #define MMF_STAMP(var)
+#define MMF_KSTAMP(var)
 #endif
 
 template <class T, class LA, class LB>
@@ -295,7 +301,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
   if (nk <= 0) return;
-#ifdef MMF_STAMPS
+#if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
   unsigned long long s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0;
 #endif
   la.load(0);
@@ -320,11 +326,11 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     MMF_STAMP(t3);
     __syncthreads();
     MMF_STAMP(t4);
-#ifdef MMF_STAMPS
+#if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
     s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
 #endif
   }
-#ifdef MMF_STAMPS
+#if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
   if (lane == 0) {
     atomicAdd(&g_stamps[0], s_load); atomicAdd(&g_stamps[1], s_mfma);
     atomicAdd(&g_stamps[2], s_store); atomicAdd(&g_stamps[3], s_bar);
