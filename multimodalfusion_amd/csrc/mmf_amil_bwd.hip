@@ -101,6 +101,23 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
       dsr[i] = bld1(rds, ok ? (unsigned)rr * 4u : OOB, 0);     // rows beyond the bag: ds = 0 => dP = 0
     }
   }
+  // ds of the tile's rows already sits in LDS (fused prep); otherwise identical to init()
+  __device__ inline void init_lds(const GateBwdCtx& g_, int row0_, int nrows, const float* ds_lds) {
+    g = g_; row0 = row0_; tid = threadIdx.x;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const unsigned bytes = (unsigned)nrows * (unsigned)g.D * 4u;
+    ra = make_rsrc(g.a, bytes);
+    rb = make_rsrc(g.gated ? g.b : g.a, bytes);
+    rwc = make_rsrc(g.Wc, (unsigned)g.D * 4u);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      int rl = Map::row(tid, i), rr = row0 + rl;
+      bool ok = Map::valid(tid, i) && rr < nrows;
+      voff[i] = ok ? ((unsigned)rr * (unsigned)g.D + 4u * Map::c4(tid, i)) * 4u : OOB;
+      dsr[i] = ok ? ds_lds[rl] : 0.f;
+    }
+  }
   __device__ inline void load(int kt) {
     const int nka = g.D / KC;
     part = kt >= nka ? 1 : 0;
@@ -164,14 +181,71 @@ struct LoadWab_M {
   }
 };
 
-template <class T>
+template <class T, bool FUSED>
 __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   extern __shared__ __align__(16) float lds[];
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers (FUSED only)
+  float* p_l = ds_l + T::BM;
   LoadP_K<T::BM, T::NT> la;
-  la.init(p.g, row0, (int)p.N);
+  if constexpr (FUSED) {
+    // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
+    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
+    float dmm = 0.f;
+    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
+    dmm = wave_sum(dmm);
+    float4 dm_l[4];                              // dM of this lane's columns (H <= 1024)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dm_l[q] = (4 * lane + 256 * q) < p.H ? ld4(p.dM + 4 * lane + 256 * q) : zero4();
+    float dbc = 0.f;
+    constexpr int NW = T::NT / 64;
+    for (int r0 = wave * 4; r0 < T::BM; r0 += NW * 4) {     // 4 rows per step: 4 independent loads in flight
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + r0 + u;
+        const int rc = row < p.N ? row : (int)p.N - 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * lane + 256 * q < p.H) {
+            float4 hv = ld4(p.h + (size_t)rc * p.H + 4 * lane + 256 * q);
+            acc += hv.x * dm_l[q].x + hv.y * dm_l[q].y + hv.z * dm_l[q].z + hv.w * dm_l[q].w;
+          }
+        g[u] = acc;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = wave_sum(g[u]);
+      if (lane < 4 && r0 + lane < T::BM) {
+        const int row = row0 + r0 + lane;
+        const float gv = lane == 0 ? g[0] : (lane == 1 ? g[1] : (lane == 2 ? g[2] : g[3]));
+        float pi = 0.f, d = 0.f;
+        if (row < p.N) {
+          pi = __expf(p.A_raw[row] - smax) * inv;
+          d = pi * (gv - dmm) + (p.gA ? p.gA[row] : 0.f);
+          if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+        }
+        ds_l[r0 + lane] = d;
+        p_l[r0 + lane] = pi;
+        dbc += d;
+      }
+    }
+    dbc = wave_sum(dbc);
+    float* red = p_l + T::BM;
+    if (lane == 0) red[wave] = dbc;
+    __syncthreads();
+    if (tid == 0 && nt == 0) {
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w) s += red[w];
+      p.dbc_part[mt] = s;
+    }
+    la.init_lds(p.g, row0, (int)p.N, ds_l);
+  } else {
+    la.init(p.g, row0, (int)p.N);
+  }
   LoadWab_M<T::BN, T::NT> lb;
   lb.init(p.Wa, p.Wb, p.H, p.g.D, col0);
   f32x16 acc[T::MB][T::NB];
@@ -193,7 +267,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
       const int row = row0 + r + 8 * t;
       const int rc = row < p.N ? row : (int)p.N - 1;
       hv[t] = ld4(p.h + (size_t)rc * p.H + col);
-      pi[t] = p.p[rc];
+      pi[t] = FUSED ? p_l[r + 8 * t] : p.p[rc];
     }
     const float4 dm = dm4[nb];
 #pragma unroll
@@ -522,11 +596,32 @@ int launch_bwd_prep(BwdPrepParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+// launch with extra dynamic LDS behind the staging buffers (fused prep scratch)
+template <class T, class P>
+static int launch_tiled_extra(const char* name, void (*kern)(P), const P& p, int grid, int extra_bytes, hipStream_t st) {
+  const int bytes = T::LDS_BYTES + extra_bytes;
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), bytes)) return e;
+  ProfScope ps(name, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), bytes, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 template <int MB>
 static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
   using T = Tile<32 * MB, 256, 1, 8, true, false>;
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
-  return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  if (p.fused_prep)
+    return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid, (2 * T::BM + 16) * 4, st);
+  return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid, st);
+}
+
+// > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
+int bwd_dh_fused_groups(int64_t N, int H) {
+  static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
+  if (!env || !use_wide_tiles(N, H)) return 0;
+  const int mb = pick_wide_mb(N, H / 256);
+  return (int)((N + 32 * mb - 1) / (32 * mb));
 }
 
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
@@ -540,15 +635,16 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
       default: return launch_bwd_dh_wide<7>(p, st);
     }
   }
+  if (p.fused_prep) return MMF_ERR_ARG;
   const int ntn = (p.H + 127) / 128;
   if ((p.N / 128) * ntn >= 256) {
     using T = Tile<128, 128, 2, 2, true, false>;
     p.mt_count = (int)((p.N + 127) / 128); p.nt_count = ntn;
-    return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+    return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
   using T = Tile<64, 64, 2, 2, true, false>;
   p.mt_count = (int)((p.N + 63) / 64); p.nt_count = (p.H + 63) / 64;
-  return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
 int launch_nn(NnParams p, hipStream_t st) {

@@ -180,12 +180,6 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
-  BwdPrepParams bp{};
-  bp.h = w.h; bp.A_raw = A_raw; bp.stats = w.stats; bp.dM = dM; bp.M = M; bp.gA = gA;
-  bp.N = d->N; bp.H = d->H; bp.p = w.p; bp.ds = w.ds; bp.dbc_part = w.dbc_part;
-  bp.n_groups = (int)((d->N + 3) / 4 < PREP_GROUPS ? (d->N + 3) / 4 : PREP_GROUPS);
-  if (int e = launch_bwd_prep(bp, st)) return e;
-
   GateBwdCtx gc{};
   gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
   gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2);
@@ -193,6 +187,21 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
+
+  // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H);
+  if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
+    dp.fused_prep = 1;
+    dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
+    dp.p_out = w.p; dp.ds_out = w.ds; dp.dbc_part = w.dbc_part;
+  } else {
+    BwdPrepParams bp{};
+    bp.h = w.h; bp.A_raw = A_raw; bp.stats = w.stats; bp.dM = dM; bp.M = M; bp.gA = gA;
+    bp.N = d->N; bp.H = d->H; bp.p = w.p; bp.ds = w.ds; bp.dbc_part = w.dbc_part;
+    bp.n_groups = (int)((d->N + 3) / 4 < PREP_GROUPS ? (d->N + 3) / 4 : PREP_GROUPS);
+    dbc_groups = bp.n_groups;
+    if (int e = launch_bwd_prep(bp, st)) return e;
+  }
   if (int e = launch_bwd_dh(dp, st)) return e;
 
   if (g->dx) {   // d(input) = du . W1   (radio: the input is reduce_dim's output)
@@ -228,7 +237,7 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
   if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
   seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
-  seg(w.dbc_part, g->dbc, 1, bp.n_groups, 1);
+  seg(w.dbc_part, g->dbc, 1, dbc_groups, 1);
   rp.nseg = n;
   return launch_reduce(rp, st);
 }

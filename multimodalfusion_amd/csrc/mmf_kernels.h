@@ -73,7 +73,7 @@ struct GateBwdCtx {        // what the on-the-fly dP operand needs
 struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   GateBwdCtx g;
   const float *Wa, *Wb;    // [D x H]
-  const float* p;          // [N]
+  const float* p;          // [N]  (read when !fused_prep)
   const float* dM;         // [H]
   const float* h;          // [N x H]
   float* du;               // [N x H]
@@ -81,6 +81,11 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   int H;
   float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
   int mt_count, nt_count;
+  // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
+  // in LDS for its loader / epilogue and publishes them for the TN kernel
+  int fused_prep;
+  const float *A_raw, *stats, *Mpool, *gA;
+  float *p_out, *ds_out, *dbc_part;
 };
 
 enum : int { TN_A_PLAIN = 0, TN_A_GATE = 1 };
@@ -125,6 +130,7 @@ int pool_groups(int64_t N);
 int launch_pool(PoolParams p, hipStream_t st);
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
+int bwd_dh_fused_groups(int64_t N, int H);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
 int pick_wide_mb(int64_t M, int ntn);
