@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=8, help="timed bags of the CPU baseline sample")
     ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
+    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (extra key, never `value`)")
     return ap.parse_args()
 
 
@@ -121,6 +122,46 @@ def kernel_profile(step, steps):
     prof = _lib.profile_dump()
     _lib.profile_enable(False)
     return {k: dict(launches=n, avg_us=1e3 * ms / max(n, 1)) for k, (n, ms) in prof.items()}
+
+
+def h2d_leg(model, N, dev, steps, warmup):
+    """PCIe-inclusive rate (never `value`): every step takes a NEW bag from pinned host memory; (a) copied
+    synchronously at the top of the step as the reference does (utils/core_utils.py:194-198), (b) staged by
+    feed.DevicePrefetcher (side stream, 2 bags in flight) so the copy overlaps the previous bag's kernels."""
+    import torch
+    from multimodalfusion_amd.feed import DevicePrefetcher
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    host = [torch.randn(N, 1024).pin_memory() for _ in range(3)]
+    loss_fn = NLLSurvLoss(alpha=0.0)
+    Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
+
+    def run(x):
+        for p in model.parameters():
+            p.grad = None
+        hz, S, Yh, _ = model(path_features=x)
+        loss_fn(hazards=hz, S=S, Y=Y, c=c).backward()
+
+    def batches(n):
+        for i in range(n):
+            yield ({}, host[i % 3], torch.zeros(1, 1), torch.tensor([1]), None, torch.tensor([0.0]))
+
+    res = {}
+    for name in ("sync_copy", "prefetch"):
+        for phase, n in (("warm", warmup), ("timed", steps)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if name == "sync_copy":
+                for b in batches(n):
+                    run(b[1].to(dev, non_blocking=False))
+            else:
+                for b in DevicePrefetcher(batches(n), dev, depth=2):
+                    run(b[1])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        res[name] = {"bags_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps}
+    res["bytes_per_bag"] = N * 1024 * 4
+    res["h2d_gbs_prefetch"] = N * 1024 * 4 * res["prefetch"]["bags_per_s"] / 1e9
+    return res
 
 
 def cpu_baseline(N, n_bags):
@@ -256,6 +297,8 @@ def main():
                 d2 = time_steps(st2, args.steps, args.warmup, 1)
                 extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": 1e3 * d2 / args.steps}
             out["other_sizes"] = extra
+        if args.h2d and world == 1:
+            out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

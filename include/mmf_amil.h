@@ -140,6 +140,17 @@ int mmf_kron_forward(const float* const* o, int32_t m, int32_t dim, int32_t B,
 int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t dim, int32_t B,
                       float drop_p, uint32_t seed, uint32_t site, float* const* d_o, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-step tail on flat fp32 buffers: the gradient of l1_reg_all + torch.optim.Adam(weight_decay) in one launch.
+ *   replaces utils/utils.py:249-257 (l1_reg_all, through autograd) + utils/utils.py:144-146 (Adam) as used by
+ *   utils/core_utils.py:216-219,242-247.  l1_coeff = lambda_reg x (micro-batches accumulated since the last step);
+ *   step = 1-based optimizer step count.  w, m, v are updated in place.
+ * mmf_abs_sum: out[0] = sum_i |w_i| (the value of l1_reg_all); partials = 512 floats of scratch.
+ * ------------------------------------------------------------------------------------------- */
+int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float l1_coeff, int32_t step, void* stream);
+int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
  * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
  * records and returns the number of bytes written (or needed when buf == NULL). */

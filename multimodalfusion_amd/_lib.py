@@ -76,6 +76,9 @@ SYMBOLS = {
                                    C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mmf_kron_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
                                     C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mmf_adam_l1_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "mmf_abs_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
     "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),
     "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),

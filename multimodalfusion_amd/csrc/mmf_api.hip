@@ -1,6 +1,7 @@
 // C ABI (include/mmf_amil.h): argument checks, workspace carving, kernel sequencing.
 // No allocation, no host synchronisation, no global mutable state except the (mutex-guarded)
 // "dynamic LDS attribute already set" set.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,6 +109,9 @@ static int check_desc(const mmf_amil_desc* d) {
   if (d->H != 256 && d->H != 512 && d->H != 1024) return MMF_ERR_SHAPE;
   if (d->D % 128 != 0) return MMF_ERR_SHAPE;
   if (d->N * (int64_t)(d->H > d->D ? d->H : d->D) >= (int64_t)1 << 32) return MMF_ERR_SHAPE;  // 32-bit mask index
+  // buffer loads: 32-bit byte offsets, and the "reads as zero" sentinel is 2^31 => every operand < 2 GiB
+  const int64_t widest = d->L > 2 * d->D ? d->L : 2 * d->D;
+  if (d->N * widest * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
   if (d->p_h < 0.f || d->p_h >= 1.f || d->p_att < 0.f || d->p_att >= 1.f) return MMF_ERR_ARG;
   return MMF_OK;
 }
@@ -124,7 +128,7 @@ const char* mmf_strerror(int code) {
   switch (code) {
     case MMF_OK: return "ok";
     case MMF_ERR_ARG: return "invalid argument (null pointer or bad flag)";
-    case MMF_ERR_SHAPE: return "unsupported shape (need L,H % 32 == 0, H in {256,512,1024}, D % 128 == 0, K % 32 == 0)";
+    case MMF_ERR_SHAPE: return "unsupported shape (need L,H % 32 == 0, H in {256,512,1024}, D % 128 == 0, K % 32 == 0, every operand < 2 GiB)";
     case MMF_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
     case MMF_ERR_WORKSPACE: return "workspace too small (see mmf_*_workspace_bytes)";
     case MMF_ERR_LAUNCH: return "HIP launch failed";
@@ -247,6 +251,7 @@ int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, i
                        float drop_p, uint32_t drop_seed, uint32_t drop_site, float* y, void* stream) {
   if (!x_segs || nseg < 1 || nseg > 4 || !W || !y) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  if (M * (int64_t)kseg * 4 >= (int64_t)1 << 31 || (int64_t)N * nseg * kseg * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
   LinearParams lp{};
   for (int i = 0; i < nseg; ++i) {
     if (!x_segs[i]) return MMF_ERR_ARG;
@@ -279,6 +284,7 @@ int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nse
   if (dx && (nseg != 1 || !W)) return MMF_ERR_ARG;
   const int K = nseg * kseg;
   if (N % 4 != 0 || kseg % 4 != 0) return MMF_ERR_SHAPE;
+  if (M * (int64_t)(N > kseg ? N : kseg) * 4 >= (int64_t)1 << 31 || (int64_t)N * K * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int splits = linear_bwd_splits(M, N, K);
   if (splits > 1 && (!workspace || workspace_bytes < mmf_linear_backward_workspace_bytes(M, N, K))) return MMF_ERR_WORKSPACE;
@@ -341,6 +347,26 @@ int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_
   if (!risks || !times || !c || !loss || !d_risks || B < 1) return MMF_ERR_ARG;
   CoxParams p{risks, times, c, B, loss, d_risks};
   return launch_cox(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float l1_coeff, int32_t step, void* stream) {
+  if (!w || !g || !m || !v || n < 1 || step < 1) return MMF_ERR_ARG;
+  if (!aligned16(w) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return MMF_ERR_ALIGN;
+  AdamParams p{};
+  p.w = w; p.g = g; p.m = m; p.v = v; p.n = n;
+  p.b1 = beta1; p.b2 = beta2; p.eps = eps; p.wd = weight_decay; p.l1 = l1_coeff;
+  // bias corrections in double, as torch computes them on the host
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  p.step_size = (float)((double)lr / bc1);
+  p.bc2_sqrt = (float)std::sqrt(bc2);
+  return launch_adam_l1(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream) {
+  if (!w || !partials || !out || n < 1) return MMF_ERR_ARG;
+  return launch_abs_sum(w, n, partials, out, static_cast<hipStream_t>(stream));
 }
 
 static DropSpec make_drop(int kind, float p, uint32_t seed, uint32_t site) {

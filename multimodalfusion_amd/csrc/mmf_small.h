@@ -37,6 +37,16 @@ struct CoxParams {
   float *loss, *drisks;
 };
 
+struct AdamParams {
+  float *w, *m, *v;              // flat parameters and Adam moments [n]
+  const float* g;                // flat gradients [n]
+  int64_t n;
+  float b1, b2, eps, wd, l1;     // l1 = lambda_reg x accumulated micro-batches
+  float step_size, bc2_sqrt;     // lr / (1 - b1^t), sqrt(1 - b2^t)
+};
+
+int launch_adam_l1(AdamParams p, hipStream_t st);
+int launch_abs_sum(const float* w, int64_t n, float* partials, float* out, hipStream_t st);
 int launch_head_fwd(HeadParams p, hipStream_t st);
 int launch_head_bwd(HeadBwdParams p, hipStream_t st);
 int launch_nll(NllParams p, hipStream_t st);

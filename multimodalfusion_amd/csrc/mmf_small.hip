@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void cox_kernel(CoxParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-step tail: l1_reg_all's gradient + torch.optim.Adam(weight_decay) in ONE pass over the flat
+// parameter / gradient buffers (utils/utils.py:144-146,249-257; utils/core_utils.py:216-219,242-247).
+//   g' = g + l1 * sign(w) + wd * w ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
+//   w -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)          (torch's Adam, amsgrad off)
+// `l1` = lambda_reg x (micro-batches accumulated): the reference adds lambda*|W|_1 un-divided to every micro-batch's
+// loss, so autograd would have added lambda*sign(w) that many times.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_l1_kernel(AdamParams p) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= p.n) return;
+  auto upd = [&](float w, float g, float& m, float& v) {
+    const float sg = w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f);
+    const float gg = g + p.l1 * sg + p.wd * w;
+    m = p.b1 * m + (1.f - p.b1) * gg;
+    v = p.b2 * v + (1.f - p.b2) * gg * gg;
+    const float denom = sqrtf(v) / p.bc2_sqrt + p.eps;
+    return w - p.step_size * (m / denom);
+  };
+  if (i4 + 3 < p.n) {
+    float4 w = ld4(p.w + i4), g = ld4(p.g + i4), m = ld4(p.m + i4), v = ld4(p.v + i4);
+    w.x = upd(w.x, g.x, m.x, v.x); w.y = upd(w.y, g.y, m.y, v.y);
+    w.z = upd(w.z, g.z, m.z, v.z); w.w = upd(w.w, g.w, m.w, v.w);
+    st4(p.w + i4, w); st4(p.m + i4, m); st4(p.v + i4, v);
+  } else {
+    for (int64_t i = i4; i < p.n; ++i) {
+      float m = p.m[i], v = p.v[i];
+      p.w[i] = upd(p.w[i], p.g[i], m, v);
+      p.m[i] = m; p.v[i] = v;
+    }
+  }
+}
+
+// sum_i |w_i| (the value of l1_reg_all, for logging): per-block partials, then one block; fixed order
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float* w, int64_t n, float* partials, int nblocks, float* out) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  if (out == nullptr) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) acc += fabsf(w[i]);
+  } else {
+    for (int i = tid; i < nblocks; i += 256) acc += partials[i];
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float s = red[0] + red[1] + red[2] + red[3];
+    if (out) out[0] = s; else partials[blockIdx.x] = s;
+  }
+}
+
+int launch_adam_l1(AdamParams p, hipStream_t st) {
+  const int64_t blocks = (p.n + 1023) / 1024;
+  { ProfScope ps("adam_l1_kernel", st); hipLaunchKernelGGL(adam_l1_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+int launch_abs_sum(const float* w, int64_t n, float* partials, float* out, hipStream_t st) {
+  const int nb = 512;
+  { ProfScope ps("abs_sum_kernel", st);
+    hipLaunchKernelGGL(abs_sum_kernel, dim3(nb), dim3(256), 0, st, w, n, partials, nb, (float*)nullptr);
+    hipLaunchKernelGGL(abs_sum_kernel, dim3(1), dim3(256), 0, st, w, n, partials, nb, out); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 int launch_head_fwd(HeadParams p, hipStream_t st) {
   if (p.B * p.K > HEAD_MAX_BK || p.B > 256) return MMF_ERR_SHAPE;
   { ProfScope ps("surv_head_fwd_kernel", st); hipLaunchKernelGGL(surv_head_fwd_kernel, dim3(1), dim3(256), 0, st, p); }

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from ..dp import FlatGradBuffer
+from ..optim import FlatAdam
 from .loss_utils import CoxSurvLoss, NLLSurvLoss
 
 
@@ -48,13 +49,18 @@ def _to_device(radio_features, path_features, genomic_features, label, c, device
     return feats, label.to(device), c.to(device)
 
 
+def _is_sentinel(t):
+    """The dataset marks a missing modality with zeros((1, 1)) (utils/core_utils.py:185-192 of the reference).
+    Shape is checked first so that real bags (possibly already on the GPU via feed.DevicePrefetcher) cost no sync."""
+    return tuple(t.shape) == (1, 1) and not bool(t.any())
+
+
 def _skip(mode, radio_features, path_features, genomic_features):
-    z = torch.zeros((1, 1))
-    if "omic" in mode and torch.equal(genomic_features.float(), z):
+    if "omic" in mode and _is_sentinel(genomic_features):
         return True
-    if "path" in mode and torch.equal(path_features, z):
+    if "path" in mode and _is_sentinel(path_features):
         return True
-    if "radio" in mode and all(torch.equal(r, z) for r in radio_features.values()):
+    if "radio" in mode and all(_is_sentinel(r) for r in radio_features.values()):
         return True
     return False
 
@@ -85,16 +91,32 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
             loss = loss_fn(hazards=hazards, S=S, Y=label, c=c)
         else:
             raise NotImplementedError(type(loss_fn))
-        loss_reg = 0 if reg_fn is None else reg_fn(model) * lambda_reg
+        fused_tail = isinstance(optimizer, FlatAdam)
+        if fused_tail:
+            # fused per-step tail: the L1 term never enters autograd; its gradient (lambda * sign(W) per micro-batch)
+            # is added inside the Adam kernel, its value is a device scalar for logging only
+            loss_reg = optimizer.l1_value() if (reg_fn is not None and lambda_reg) else 0
+        else:
+            loss_reg = 0 if reg_fn is None else reg_fn(model) * lambda_reg
         losses.append(loss.detach())
         regs.append(loss_reg.detach() if torch.is_tensor(loss_reg) else torch.tensor(float(loss_reg), device=device))
         all_risk.append(risk.detach().reshape(-1))
         all_c.append(c.detach().reshape(-1))
         all_t.append(np.asarray(event_time).reshape(-1))
         # the reference: loss = loss / gc + loss_reg ; backward ; step every gc bags (core_utils.py:242-247)
-        (loss / (gc * world) + loss_reg).backward()
+        if fused_tail:
+            (loss / (gc * world)).backward()
+        else:
+            (loss / (gc * world) + loss_reg).backward()
         seen += 1
         if seen % gc == 0:
+            if fused_tail:
+                if world > 1:
+                    optimizer.all_reduce()
+                optimizer.lambda_l1 = lambda_reg if reg_fn is not None else 0.0
+                optimizer.step(l1_micro_batches=gc * world)
+                optimizer.zero_grad()
+                continue
             if grad_buffer is not None and world > 1:
                 grad_buffer.all_reduce()
             optimizer.step()
