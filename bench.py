@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=8, help="timed bags of the CPU baseline sample")
     ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
+    ap.add_argument("--graph", action="store_true", help="also time N = 1k / 10k as captured hipGraph steps (extra key)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (extra key, never `value`)")
     return ap.parse_args()
 
@@ -122,6 +123,46 @@ def kernel_profile(step, steps):
     prof = _lib.profile_dump()
     _lib.profile_enable(False)
     return {k: dict(launches=n, avg_us=1e3 * ms / max(n, 1)) for k, (n, ms) in prof.items()}
+
+
+def graph_leg(model, dev, steps, gen):
+    """Small bags are host-bound in eager mode; the same train-mode step captured into ONE hipGraph
+    (graph.GraphedStep: device-resident dropout seed, fresh masks per replay) shows the GPU-side rate."""
+    import torch
+    from multimodalfusion_amd.graph import GraphedStep
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    loss_fn = NLLSurvLoss(alpha=0.0)
+    Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
+    res = {}
+    for n in (1000, 10000):
+        x = torch.randn(n, 1024, device=dev, generator=gen)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+
+        def fn():
+            for p in model.parameters():
+                p.grad.zero_()
+            hz, S, Yh, _ = model(path_features=x)
+            loss = loss_fn(hazards=hz, S=S, Y=Y, c=c)
+            loss.backward()
+            return loss
+
+        gs = GraphedStep(fn)
+        try:
+            for _ in range(5):
+                gs()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gs()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gs.close()
+        res[str(n)] = {"bags_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps}
+    for p in model.parameters():
+        p.grad = None
+    return res
 
 
 def h2d_leg(model, N, dev, steps, warmup):
@@ -297,6 +338,8 @@ def main():
                 d2 = time_steps(st2, args.steps, args.warmup, 1)
                 extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": 1e3 * d2 / args.steps}
             out["other_sizes"] = extra
+        if args.graph and world == 1:
+            out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
         if args.h2d and world == 1:
             out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup)
         if world == 1 and not args.no_cpu_baseline:

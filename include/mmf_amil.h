@@ -151,6 +151,11 @@ int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, fl
                      float eps, float weight_decay, float l1_coeff, int32_t step, void* stream);
 int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream);
 
+/* Graph-replay-safe dropout.  By-value seeds are frozen into a captured hipGraph; with a device word registered here
+ * every kernel adds *seed_dev to its dropout keys (effective seed = seed argument + *seed_dev, uint32 wrap), so a
+ * graph whose first node increments that word draws fresh masks per replay.  NULL = off (default).  Process-wide. */
+void mmf_set_device_seed(const uint32_t* seed_dev);
+
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
  * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
  * records and returns the number of bytes written (or needed when buf == NULL). */

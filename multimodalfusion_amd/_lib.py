@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmf_amil.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -79,6 +79,7 @@ SYMBOLS = {
     "mmf_adam_l1_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "mmf_abs_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_set_device_seed": (None, [C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
     "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),
     "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),

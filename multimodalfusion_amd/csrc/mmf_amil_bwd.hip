@@ -85,7 +85,7 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   float dsr[Map::NV];
   float4 ra4[Map::NV], rb4[Map::NV], wc4;
   __device__ inline void init(const GateBwdCtx& g_, int row0_, int nrows) {
-    g = g_; row0 = row0_; tid = threadIdx.x;
+    g = g_; g.resolve_seed(); row0 = row0_; tid = threadIdx.x;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     const unsigned bytes = (unsigned)nrows * (unsigned)g.D * 4u;
@@ -103,7 +103,7 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   }
   // ds of the tile's rows already sits in LDS (fused prep); otherwise identical to init()
   __device__ inline void init_lds(const GateBwdCtx& g_, int row0_, int nrows, const float* ds_lds) {
-    g = g_; row0 = row0_; tid = threadIdx.x;
+    g = g_; g.resolve_seed(); row0 = row0_; tid = threadIdx.x;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     const unsigned bytes = (unsigned)nrows * (unsigned)g.D * 4u;
@@ -373,7 +373,7 @@ struct LoadA_M_Gate {
   float dsr[Map::NV];
   float4 csum_a, csum_b, csum2;   // column sums: d pre-tanh, d pre-sigmoid (bias grads), ds.a_d.b_d (dWc)
   __device__ inline void init(const GateBwdCtx& g_, int d0_, int kbase_, int kmax, bool do_sum_) {
-    g = g_; d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
+    g = g_; g.resolve_seed(); d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     csum_a = zero4(); csum_b = zero4(); csum2 = zero4();

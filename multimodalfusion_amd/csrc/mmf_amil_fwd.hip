@@ -48,6 +48,7 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 
   const uint32_t thr = drop_threshold(p.drop_p);
   const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const uint32_t dkey = p.drop_key + (p.seed_dev ? *p.seed_dev : 0u);   // device-resident part of the seed, if any
   float4 bias4[T::NB];                       // per column strip, loaded once, before any store
 #pragma unroll
   for (int nb = 0; nb < T::NB; ++nb) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         y[e] = apply_act(y[e], p.act);
-        if (p.drop_p > 0.f) y[e] = keep(p.drop_key, idx + e, thr) ? y[e] * scale : 0.f;
+        if (p.drop_p > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
       st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
     }
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   const uint32_t thr = drop_threshold(p.drop_p);
   const bool drop = p.drop_p > 0.f;
   const float dscale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const uint32_t sdev = p.seed_dev ? *p.seed_dev : 0u;
+  const uint32_t key_a = p.key_a + sdev, key_b = p.key_b + sdev;
   float* blk = lds + wave * (32 * EPI_STRIDE);
   float* sred = lds + (T::NT / 64) * (32 * EPI_STRIDE);   // [WN][BM] row partials, behind the transpose scratch
 
@@ -191,8 +194,8 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
           for (int e = 0; e < 4; ++e) {
             float ad = av[e], bd = bv[e];
             if (drop) {
-              ad = keep(p.key_a, idx + e, thr) ? ad * dscale : 0.f;
-              if constexpr (GATED) bd = keep(p.key_b, idx + e, thr) ? bd * dscale : 0.f;
+              ad = keep(key_a, idx + e, thr) ? ad * dscale : 0.f;
+              if constexpr (GATED) bd = keep(key_b, idx + e, thr) ? bd * dscale : 0.f;
             }
             rowsum[q] += ad * bd * wc[e];
           }
@@ -372,7 +375,8 @@ int pick_wide_mb(int64_t M, int ntn) {
 }
 bool use_wide_tiles(int64_t M, int N) {
   static const int env = getenv("MMF_WIDE") ? atoi(getenv("MMF_WIDE")) : 1;
-  return env && N % 256 == 0 && M * (int64_t)(N / 256) >= 64 * 256;
+  static const int min_rows = getenv("MMF_WIDE_MIN") ? atoi(getenv("MMF_WIDE_MIN")) : 64 * 256;   // tuning override
+  return env && N % 256 == 0 && M * (int64_t)(N / 256) >= min_rows;
 }
 
 template <int MB>

@@ -31,6 +31,9 @@ int set_dyn_lds(const void* kern, int bytes) {
   return MMF_OK;
 }
 
+// optional device-resident dropout seed (mmf_set_device_seed): every launch folds it into its keys
+static const uint32_t* g_seed_dev = nullptr;
+
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
@@ -122,7 +125,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 1; }
+int mmf_abi_version(void) { return 2; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -155,14 +158,14 @@ int mmf_amil_forward(const mmf_amil_desc* d, const float* x, void* workspace, si
   lp.x[0] = x; lp.nseg = 1; lp.kseg = d->L; lp.ldx = d->L;
   lp.w = d->W1; lp.bias = d->b1; lp.y = w.h;
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
-  lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0);
+  lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = g_seed_dev;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
   gp.h = w.h; gp.Wa = d->Wa; gp.ba = d->ba; gp.Wb = d->Wb; gp.bb = d->bb; gp.Wc = d->Wc;
   gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
   gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
-  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2);
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = g_seed_dev;
   if (int e = launch_gate_fwd(gp, st)) return e;
 
   PoolParams pp{};
@@ -186,7 +189,7 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
 
   GateBwdCtx gc{};
   gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
-  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2);
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = g_seed_dev;
 
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
@@ -261,7 +264,7 @@ int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, i
   if (!aligned16(W)) return MMF_ERR_ALIGN;
   lp.nseg = nseg; lp.kseg = kseg; lp.ldx = kseg;
   lp.w = W; lp.bias = bias; lp.y = y; lp.M = M; lp.N = N; lp.K = nseg * kseg;
-  lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site);
+  lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site); lp.seed_dev = g_seed_dev;
   return launch_linear(lp, static_cast<hipStream_t>(stream));
 }
 
@@ -374,6 +377,7 @@ static DropSpec make_drop(int kind, float p, uint32_t seed, uint32_t site) {
   d.kind = p > 0.f ? kind : 0;
   d.p = p;
   d.key = drop_key(seed, site);
+  d.dev = g_seed_dev;
   return d;
 }
 
@@ -426,6 +430,11 @@ int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t 
 void mmf_debug_stamps(int which, unsigned long long* out8) {
   if (which == 0) debug_stamps_fwd(out8); else debug_stamps_bwd(out8);
 }
+
+/* Graph-replay-safe dropout: when a device pointer is set, every kernel adds *seed_dev to its dropout keys, so a
+ * captured hipGraph whose first node bumps that word draws fresh masks on every replay (by-value seeds are frozen
+ * into the captured kernel arguments).  NULL restores the default.  Process-wide; set it before capture. */
+void mmf_set_device_seed(const uint32_t* seed_dev) { g_seed_dev = seed_dev; }
 
 void mmf_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof_mu);

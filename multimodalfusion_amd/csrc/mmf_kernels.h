@@ -19,6 +19,7 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   int act;
   float drop_p;
   uint32_t drop_key;
+  const uint32_t* seed_dev;   // optional device-resident seed added to every key (graph-replay-safe dropout), or null
   int mt_count, nt_count;
 };
 
@@ -31,6 +32,7 @@ struct GateFwdParams {
   int H, D, gated;
   float drop_p;            // dropout on a / b (model_modules.py:97-99), 0 = off
   uint32_t key_a, key_b;
+  const uint32_t* seed_dev;
   int mt_count, nt_count;
 };
 
@@ -68,6 +70,11 @@ struct GateBwdCtx {        // what the on-the-fly dP operand needs
   int D, gated;
   float drop_p;
   uint32_t key_a, key_b;
+  const uint32_t* seed_dev;
+  // loaders call this once on their private copy: fold the device-resident seed into the keys
+  __device__ inline void resolve_seed() {
+    if (seed_dev) { const uint32_t sd = *seed_dev; key_a += sd; key_b += sd; seed_dev = nullptr; }
+  }
 };
 
 struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h

@@ -5,7 +5,10 @@
 
 namespace mmf {
 
-struct DropSpec { int kind; float p; uint32_t key; };   // kind: 0 none, 1 Dropout, 2 AlphaDropout
+struct DropSpec {            // kind: 0 none, 1 Dropout, 2 AlphaDropout
+  int kind; float p; uint32_t key;
+  const uint32_t* dev;       // optional device-resident seed added to the key (graph-replay-safe dropout)
+};
 
 struct DenseParams {
   const float *x, *W, *bias;

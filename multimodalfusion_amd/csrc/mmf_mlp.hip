@@ -47,7 +47,7 @@ __host__ __device__ inline DropAffine alpha_affine(float p) {
 }
 __device__ inline float drop_fwd(float y, const DropSpec& d, uint32_t idx) {
   if (d.kind == 0) return y;
-  const bool k = keep(d.key, idx, drop_threshold(d.p));
+  const bool k = keep(d.key + (d.dev ? *d.dev : 0u), idx, drop_threshold(d.p));
   if (d.kind == 1) return k ? y / (1.0f - d.p) : 0.f;
   DropAffine af = alpha_affine(d.p);
   return af.a * (k ? y : af.alpha_p) + af.b;
@@ -55,7 +55,7 @@ __device__ inline float drop_fwd(float y, const DropSpec& d, uint32_t idx) {
 // (d out / d y, and y recovered from the dropped output) for backward
 __device__ inline void drop_bwd(float yd, const DropSpec& d, uint32_t idx, float& dydy, float& y) {
   if (d.kind == 0) { dydy = 1.f; y = yd; return; }
-  const bool k = keep(d.key, idx, drop_threshold(d.p));
+  const bool k = keep(d.key + (d.dev ? *d.dev : 0u), idx, drop_threshold(d.p));
   if (d.kind == 1) { dydy = k ? 1.0f / (1.0f - d.p) : 0.f; y = k ? yd * (1.0f - d.p) : 0.f; return; }
   DropAffine af = alpha_affine(d.p);
   dydy = k ? af.a : 0.f;
