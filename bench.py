@@ -261,8 +261,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("MMF_BENCH_REHEARSAL") == "1":
+            # rehearsal of the multi-process path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -303,7 +309,9 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ----
-        prof = kernel_profile(step, max(5, min(args.steps, 20)))
+        # rank 0 only: this leg must NOT contain the collective (the other ranks are already at the final barrier)
+        local_step = make_step(model, x, dev, flat, 1)
+        prof = kernel_profile(local_step, max(5, min(args.steps, 20)))
         dom = max(prof.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0] if prof else None
         kflops = {
             "linear_nt_kernel": 2 * 1024 * 256 * N,
