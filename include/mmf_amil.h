@@ -151,6 +151,25 @@ int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, fl
                      float eps, float weight_decay, float l1_coeff, int32_t step, void* stream);
 int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream);
 
+/* Fused per-modality gating stage of XlinearFusion (models/model_modules.py:158-165), all m <= 3 modalities in ONE
+ * single-workgroup launch:  h_i = relu(Wh_i v_i + bh_i); z_i = Wz_i [v_0|..|v_{m-1}] + bz_i;
+ * gm_i = sigmoid(z_i) * h_i;  o_i = Dropout(relu(Wo_i gm_i + bo_i))  (dropout site i of `seed`).
+ * forward writes h, z, gm, o ([B x sdim] each); backward reads them plus d_o and writes dv (incl. the v_cat path) and
+ * every weight gradient.  All arrays are indexed by modality; entries >= m are ignored.  B * m * sdim <= 384. */
+typedef struct mmf_xreduce_io {
+  int32_t m, B, dim, sdim;
+  const float* v[3];
+  const float* Wh[3]; const float* bh[3];
+  const float* Wz[3]; const float* bz[3];
+  const float* Wo[3]; const float* bo[3];
+  float* h[3]; float* z[3]; float* gm[3]; float* o[3];
+  const float* d_o[3];
+  float* dv[3];
+  float* dWh[3]; float* dbh[3]; float* dWz[3]; float* dbz[3]; float* dWo[3]; float* dbo[3];
+} mmf_xreduce_io;
+int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
+int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
+
 /* Graph-replay-safe dropout.  By-value seeds are frozen into a captured hipGraph; with a device word registered here
  * every kernel adds *seed_dev to its dropout keys (effective seed = seed argument + *seed_dev, uint32 wrap), so a
  * graph whose first node increments that word draws fresh masks per replay.  NULL = off (default).  Process-wide. */

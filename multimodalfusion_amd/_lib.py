@@ -36,6 +36,14 @@ class AmilGrads(C.Structure):
     ]
 
 
+class XReduceIO(C.Structure):
+    """struct mmf_xreduce_io (include/mmf_amil.h)."""
+    _P3 = C.c_void_p * 3
+    _fields_ = [("m", C.c_int32), ("B", C.c_int32), ("dim", C.c_int32), ("sdim", C.c_int32)] + [
+        (n, C.c_void_p * 3) for n in ("v", "Wh", "bh", "Wz", "bz", "Wo", "bo", "h", "z", "gm", "o", "d_o", "dv",
+                                      "dWh", "dbh", "dWz", "dbz", "dWo", "dbo")]
+
+
 # name -> (restype, argtypes): every symbol include/mmf_amil.h declares
 SYMBOLS = {
     "mmf_strerror": (C.c_char_p, [C.c_int]),
@@ -79,6 +87,8 @@ SYMBOLS = {
     "mmf_adam_l1_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
     "mmf_abs_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_xreduce_forward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
+    "mmf_xreduce_backward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
     "mmf_set_device_seed": (None, [C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
     "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -431,6 +431,39 @@ void mmf_debug_stamps(int which, unsigned long long* out8) {
   if (which == 0) debug_stamps_fwd(out8); else debug_stamps_bwd(out8);
 }
 
+static int xreduce_params(const mmf_xreduce_io* io, float drop_p, uint32_t seed, bool bwd, XReduceParams& p) {
+  if (!io || io->m < 1 || io->m > 3 || io->B < 1 || io->dim < 1 || io->sdim < 1) return MMF_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  p = XReduceParams{};
+  p.m = io->m; p.B = io->B; p.dim = io->dim; p.sdim = io->sdim;
+  for (int i = 0; i < io->m; ++i) {
+    if (!io->v[i] || !io->Wh[i] || !io->bh[i] || !io->Wz[i] || !io->bz[i] || !io->Wo[i] || !io->bo[i]) return MMF_ERR_ARG;
+    if (!io->h[i] || !io->z[i] || !io->gm[i] || !io->o[i]) return MMF_ERR_ARG;
+    p.v[i] = io->v[i]; p.Wh[i] = io->Wh[i]; p.bh[i] = io->bh[i]; p.Wz[i] = io->Wz[i]; p.bz[i] = io->bz[i];
+    p.Wo[i] = io->Wo[i]; p.bo[i] = io->bo[i];
+    p.h[i] = io->h[i]; p.z[i] = io->z[i]; p.gm[i] = io->gm[i]; p.o[i] = io->o[i];
+    if (bwd) {
+      if (!io->d_o[i] || !io->dv[i] || !io->dWh[i] || !io->dbh[i] || !io->dWz[i] || !io->dbz[i] || !io->dWo[i] || !io->dbo[i])
+        return MMF_ERR_ARG;
+      p.d_o[i] = io->d_o[i]; p.dv[i] = io->dv[i];
+      p.dWh[i] = io->dWh[i]; p.dbh[i] = io->dbh[i]; p.dWz[i] = io->dWz[i]; p.dbz[i] = io->dbz[i];
+      p.dWo[i] = io->dWo[i]; p.dbo[i] = io->dbo[i];
+    }
+  }
+  p.drop = make_drop(1, drop_p, seed, 0);
+  return MMF_OK;
+}
+int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream) {
+  XReduceParams p;
+  if (int e = xreduce_params(io, drop_p, seed, false, p)) return e;
+  return launch_xreduce_fwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream) {
+  XReduceParams p;
+  if (int e = xreduce_params(io, drop_p, seed, true, p)) return e;
+  return launch_xreduce_bwd(p, static_cast<hipStream_t>(stream));
+}
+
 /* Graph-replay-safe dropout: when a device pointer is set, every kernel adds *seed_dev to its dropout keys, so a
  * captured hipGraph whose first node bumps that word draws fresh masks on every replay (by-value seeds are frozen
  * into the captured kernel arguments).  NULL restores the default.  Process-wide; set it before capture. */

@@ -39,3 +39,23 @@ int launch_kron_fwd(KronParams p, hipStream_t st);
 int launch_kron_bwd(KronParams p, hipStream_t st);
 
 }  // namespace mmf
+
+namespace mmf {
+// Fused per-modality gating stage of XlinearFusion (models/model_modules.py:158-165), all m modalities in ONE launch:
+//   h_i = relu(Wh_i v_i + bh_i) ; z_i = Wz_i v_cat + bz_i ; gm_i = sigmoid(z_i) * h_i ; o_i = drop(relu(Wo_i gm_i + bo_i))
+struct XReduceParams {
+  int m, B, dim, sdim;                  // modalities (2|3), batch, 256, 16
+  const float* v[3];                    // [B x dim]
+  const float *Wh[3], *bh[3];           // [sdim x dim]
+  const float *Wz[3], *bz[3];           // [sdim x m*dim]
+  const float *Wo[3], *bo[3];           // [sdim x sdim]
+  float *h[3], *z[3], *gm[3], *o[3];    // [B x sdim] (forward outputs / backward inputs)
+  // backward
+  const float* d_o[3];                  // [B x sdim]
+  float* dv[3];                         // [B x dim]  (overwritten: includes the v_cat contribution)
+  float *dWh[3], *dbh[3], *dWz[3], *dbz[3], *dWo[3], *dbo[3];
+  DropSpec drop;                        // key of site 0; site i uses key + i*0x632BE5AB (see drop_key)
+};
+int launch_xreduce_fwd(XReduceParams p, hipStream_t st);
+int launch_xreduce_bwd(XReduceParams p, hipStream_t st);
+}  // namespace mmf

@@ -189,6 +189,129 @@ __global__ __launch_bounds__(64) void kron_bwd_kernel(KronParams p) {
   if (lane == 0) p.d[t][(size_t)b * p.dim + i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused gating stage (single workgroup; the whole stage is ~100 kFLOP: one launch instead of 4 per modality)
+// ---------------------------------------------------------------------------------------------
+constexpr int XR_MAX = 3 * 8 * 16;     // m * B * sdim values kept in LDS
+__device__ inline DropSpec site_drop(const DropSpec& d, int i) {
+  DropSpec r = d;
+  r.key = d.key + 0x632BE5ABu * (uint32_t)i;
+  return r;
+}
+__device__ inline float wave_dot(const float* a, const float* b, int n, int lane) {
+  float acc = 0.f;
+  for (int k = lane; k < n; k += 64) acc += a[k] * b[k];
+  return wave_sum(acc);
+}
+
+__global__ __launch_bounds__(256) void xreduce_fwd_kernel(XReduceParams p) {
+  __shared__ float sh_h[XR_MAX], sh_z[XR_MAX], sh_gm[XR_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = p.sdim, per = p.B * S, total = p.m * per;
+  // h and z: one wave per output value
+  for (int o = wave; o < 2 * total; o += 4) {
+    const bool is_z = o >= total;
+    const int q = is_z ? o - total : o;
+    const int i = q / per, b = (q % per) / S, j = q % S;
+    float acc;
+    if (!is_z) {
+      acc = wave_dot(p.v[i] + (size_t)b * p.dim, p.Wh[i] + (size_t)j * p.dim, p.dim, lane) + p.bh[i][j];
+      acc = fmaxf(acc, 0.f);
+    } else {
+      acc = 0.f;
+      for (int t = 0; t < p.m; ++t)      // v_cat = [v_0 | v_1 | ...]
+        acc += wave_dot(p.v[t] + (size_t)b * p.dim, p.Wz[i] + (size_t)j * p.m * p.dim + (size_t)t * p.dim, p.dim, lane);
+      acc += p.bz[i][j];
+    }
+    if (lane == 0) (is_z ? sh_z : sh_h)[q] = acc;
+  }
+  __syncthreads();
+  for (int q = tid; q < total; q += 256) {
+    const int i = q / per, r = q % per;
+    const float g = (1.0f / (1.0f + expf(-sh_z[q]))) * sh_h[q];
+    sh_gm[q] = g;
+    p.h[i][r] = sh_h[q]; p.z[i][r] = sh_z[q]; p.gm[i][r] = g;
+  }
+  __syncthreads();
+  for (int q = tid; q < total; q += 256) {
+    const int i = q / per, r = q % per, b = r / S, j = r % S;
+    float acc = p.bo[i][j];
+    for (int t = 0; t < S; ++t) acc += sh_gm[i * per + b * S + t] * p.Wo[i][j * S + t];
+    acc = fmaxf(acc, 0.f);
+    p.o[i][r] = drop_fwd(acc, site_drop(p.drop, i), (uint32_t)r);
+  }
+}
+
+__global__ __launch_bounds__(256) void xreduce_bwd_kernel(XReduceParams p) {
+  __shared__ float sh_dpo[XR_MAX], sh_dgm[XR_MAX], sh_dz[XR_MAX], sh_dph[XR_MAX];
+  const int tid = threadIdx.x;
+  const int S = p.sdim, per = p.B * S, total = p.m * per, KZ = p.m * p.dim;
+  for (int q = tid; q < total; q += 256) {         // d(pre-activation of o)
+    const int i = q / per, r = q % per;
+    float dydy, y;
+    drop_bwd(p.o[i][r], site_drop(p.drop, i), (uint32_t)r, dydy, y);
+    sh_dpo[q] = p.d_o[i][r] * dydy * (y > 0.f ? 1.f : 0.f);
+  }
+  __syncthreads();
+  for (int q = tid; q < total; q += 256) {         // d gm = dpo . Wo ; then dz, dh
+    const int i = q / per, r = q % per, b = r / S, t = r % S;
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc += sh_dpo[i * per + b * S + j] * p.Wo[i][j * S + t];
+    sh_dgm[q] = acc;
+    const float hv = p.h[i][r], sg = 1.0f / (1.0f + expf(-p.z[i][r]));
+    sh_dz[q] = acc * hv * sg * (1.f - sg);
+    sh_dph[q] = hv > 0.f ? acc * sg : 0.f;         // d(pre-activation of h)
+  }
+  __syncthreads();
+  // small weight grads: dWo [S x S], dbo, dbh, dbz
+  for (int q = tid; q < p.m * S * S; q += 256) {
+    const int i = q / (S * S), j = (q / S) % S, t = q % S;
+    float acc = 0.f;
+    for (int b = 0; b < p.B; ++b) acc += sh_dpo[i * per + b * S + j] * p.gm[i][b * S + t];
+    p.dWo[i][j * S + t] = acc;
+  }
+  for (int q = tid; q < p.m * S; q += 256) {
+    const int i = q / S, j = q % S;
+    float a = 0.f, bsum = 0.f, c = 0.f;
+    for (int b = 0; b < p.B; ++b) { a += sh_dpo[i * per + b * S + j]; bsum += sh_dph[i * per + b * S + j]; c += sh_dz[i * per + b * S + j]; }
+    p.dbo[i][j] = a; p.dbh[i][j] = bsum; p.dbz[i][j] = c;
+  }
+  // dWh [S x dim], dWz [S x m*dim], dv [B x dim]: threads along the long dimension
+  for (int i = 0; i < p.m; ++i) {
+    for (int q = tid; q < S * p.dim; q += 256) {
+      const int j = q / p.dim, k = q % p.dim;
+      float acc = 0.f;
+      for (int b = 0; b < p.B; ++b) acc += sh_dph[i * per + b * S + j] * p.v[i][(size_t)b * p.dim + k];
+      p.dWh[i][q] = acc;
+    }
+    for (int q = tid; q < S * KZ; q += 256) {
+      const int j = q / KZ, k = q % KZ, t = k / p.dim, kk = k % p.dim;
+      float acc = 0.f;
+      for (int b = 0; b < p.B; ++b) acc += sh_dz[i * per + b * S + j] * p.v[t][(size_t)b * p.dim + kk];
+      p.dWz[i][q] = acc;
+    }
+  }
+  for (int q = tid; q < p.m * p.B * p.dim; q += 256) {      // dv_t = dph_t . Wh_t + sum_i dz_i . Wz_i[:, t-th block]
+    const int t = q / (p.B * p.dim), b = (q / p.dim) % p.B, k = q % p.dim;
+    float acc = 0.f;
+    for (int j = 0; j < S; ++j) acc += sh_dph[t * per + b * S + j] * p.Wh[t][(size_t)j * p.dim + k];
+    for (int i = 0; i < p.m; ++i)
+      for (int j = 0; j < S; ++j) acc += sh_dz[i * per + b * S + j] * p.Wz[i][(size_t)j * KZ + (size_t)t * p.dim + k];
+    p.dv[t][(size_t)b * p.dim + k] = acc;
+  }
+}
+
+int launch_xreduce_fwd(XReduceParams p, hipStream_t st) {
+  if (p.m * p.B * p.sdim > XR_MAX || p.m < 1 || p.m > 3) return MMF_ERR_SHAPE;
+  { ProfScope ps("xreduce_fwd_kernel", st); hipLaunchKernelGGL(xreduce_fwd_kernel, dim3(1), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+int launch_xreduce_bwd(XReduceParams p, hipStream_t st) {
+  if (p.m * p.B * p.sdim > XR_MAX || p.m < 1 || p.m > 3) return MMF_ERR_SHAPE;
+  { ProfScope ps("xreduce_bwd_kernel", st); hipLaunchKernelGGL(xreduce_bwd_kernel, dim3(1), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 int launch_dense_fwd(DenseParams p, hipStream_t st) {
@@ -199,8 +322,64 @@ int launch_dense_fwd(DenseParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+// One launch for the whole dense backward: blocks [0, nbx*B) compute dx rows, the rest compute dW rows (+ db);
+// dpre = dy . drop' . act'(y) is rebuilt through LDS by whoever needs it instead of a separate pass
+// (the layers are tiny: three launches of ~7 us each per layer were the cost, not the arithmetic).
+constexpr int DENSE_MAX_N = 2048, DENSE_MAX_B = 256;
+__device__ inline float dense_dpre_at(const DenseBwdParams& p, int b, int n) {
+  const int64_t o = (int64_t)b * p.N + n;
+  float dydy, y;
+  drop_bwd(p.y[o], p.drop, (uint32_t)o, dydy, y);
+  return p.dy[o] * dydy * act_grad_from_y(y, p.act);
+}
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdParams p, int nbx, int dx_blocks) {
+  __shared__ float sh[DENSE_MAX_N];
+  const int tid = threadIdx.x;
+  int id = blockIdx.x;
+  if (id < dx_blocks) {                       // ---- dx[b][k] = sum_n dpre[b][n] W[n][k]
+    const int b = id / nbx, k = (id % nbx) * 256 + tid;
+    for (int n = tid; n < p.N; n += 256) sh[n] = dense_dpre_at(p, b, n);
+    __syncthreads();
+    if (k >= p.K) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = 0;
+    for (; n + 3 < p.N; n += 4) {
+      a0 += sh[n] * p.W[(size_t)n * p.K + k];
+      a1 += sh[n + 1] * p.W[(size_t)(n + 1) * p.K + k];
+      a2 += sh[n + 2] * p.W[(size_t)(n + 2) * p.K + k];
+      a3 += sh[n + 3] * p.W[(size_t)(n + 3) * p.K + k];
+    }
+    for (; n < p.N; ++n) a0 += sh[n] * p.W[(size_t)n * p.K + k];
+    p.dx[(size_t)b * p.K + k] = (a0 + a1) + (a2 + a3);
+  } else {                                    // ---- dW[n][k] = sum_b dpre[b][n] x[b][k] ; db[n] = sum_b dpre[b][n]
+    id -= dx_blocks;
+    const int n = id / nbx, kb = id % nbx, k = kb * 256 + tid;
+    if (tid < p.B) sh[tid] = dense_dpre_at(p, tid, n);
+    __syncthreads();
+    if (k < p.K) {
+      float acc = 0.f;
+      for (int b = 0; b < p.B; ++b) acc += sh[b] * p.x[(size_t)b * p.K + k];
+      p.dW[(size_t)n * p.K + k] = acc;
+    }
+    if (p.db && kb == 0 && tid == 0) {
+      float acc = 0.f;
+      for (int b = 0; b < p.B; ++b) acc += sh[b];
+      p.db[n] = acc;
+    }
+  }
+}
+
 int launch_dense_bwd(DenseBwdParams p, hipStream_t st) {
   const int64_t total = (int64_t)p.B * p.N;
+  if (p.N <= DENSE_MAX_N && p.B <= DENSE_MAX_B) {
+    const int nbx = cdiv(p.K, 256);
+    const int dx_blocks = p.dx ? nbx * p.B : 0;
+    const int dw_blocks = p.dW ? nbx * p.N : 0;
+    if (dx_blocks + dw_blocks == 0) return MMF_OK;
+    { ProfScope ps("dense_bwd_kernel", st);
+      hipLaunchKernelGGL(dense_bwd_kernel, dim3(dx_blocks + dw_blocks), dim3(256), 0, st, p, nbx, dx_blocks); }
+    return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+  }
   { ProfScope ps("dense_dpre_kernel", st); hipLaunchKernelGGL(dense_dpre_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p); }
   if (p.dx) { ProfScope ps("dense_dx_kernel", st); hipLaunchKernelGGL(dense_dx_kernel, dim3(cdiv(p.K, 256), p.B), dim3(256), 0, st, p); }
   if (p.dW) { ProfScope ps("dense_dw_kernel", st); hipLaunchKernelGGL(dense_dw_kernel, dim3(cdiv(p.K, 256), p.N), dim3(256), 0, st, p); }

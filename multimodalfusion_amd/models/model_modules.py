@@ -113,6 +113,13 @@ class XlinearFusion(nn.Module):
             seed = ops.next_dropout_seed()
         seed = seed or 0
         p = self.dropout_rate if tr else 0.0
+        if self.skip:          # the configuration the heads use: the whole block as one autograd node
+            weights = []
+            for i in range(len(v_list)):
+                for lin in (self.reduce[i][0][0], self.reduce[i][1][0], self.reduce[i][2][0]):
+                    weights += [lin.weight, lin.bias]
+            weights += [self.encoder1[0].weight, self.encoder1[0].bias, self.encoder2[0].weight, self.encoder2[0].bias]
+            return ops.xfusion(list(v_list), weights, p=p, seed=seed)
         kind = "dropout" if tr else "none"
         v_cat = torch.cat(v_list, dim=1)
         o_list = []

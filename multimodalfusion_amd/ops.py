@@ -335,3 +335,107 @@ class KronFn(torch.autograd.Function):
 
 def kron_ones(os_, drop_p=0.0, seed=0, site=0):
     return KronFn.apply(drop_p, seed, site, *os_)
+
+
+# ---- raw (no-autograd) launch helpers shared by the fused fusion Function --------------------------------------
+def _dense_fwd_raw(x, W, b, act, kind, p, seed, site):
+    B, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    check(lib().mmf_dense_forward(ptr(x), ptr(W), ptr(b), B, K, N, ACT[act], DROP_KIND[kind], float(p), seed, site,
+                                  ptr(y), stream_ptr()), "mmf_dense_forward")
+    return y
+
+
+def _dense_bwd_raw(gy, y, x, W, has_bias, act, kind, p, seed, site, need_dx=True):
+    B, K = x.shape
+    N = W.shape[0]
+    dpre = torch.empty_like(y)
+    dx = torch.empty_like(x) if need_dx else None
+    dW = torch.empty_like(W)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None
+    check(lib().mmf_dense_backward(ptr(gy), ptr(y), ptr(x), ptr(W), B, K, N, ACT[act], DROP_KIND[kind], float(p), seed,
+                                   site, ptr(dpre), ptr(dx), ptr(dW), ptr(db), stream_ptr()), "mmf_dense_backward")
+    return dx, dW, db
+
+
+class XFusionFn(torch.autograd.Function):
+    """The whole XlinearFusion block (models/model_modules.py:156-178, gate=1, skip=1) as ONE autograd node: the same
+    HIP kernels as the composable ops above, but one Python forward and one Python backward instead of ~25 nodes
+    (the block is latency-bound; at B = 1 the autograd/ctypes dispatch dominated it).
+
+    params: per modality (Wh, bh, Wz, bz, Wo, bo), then We1, be1, We2, be2.  Dropout sites: o_i -> i, post-fusion -> 8,
+    encoder1 -> 9, encoder2 -> 10 (same as the composable path)."""
+
+    @staticmethod
+    def forward(ctx, m, p, seed, *tensors):
+        vs = [_f32c(t) for t in tensors[:m]]
+        w = [_f32c(t) for t in tensors[m:]]
+        kind = "dropout" if p > 0 else "none"
+        seed = int(seed) & 0xFFFFFFFF
+        B = vs[0].shape[0]
+        sdim = w[0].shape[0]
+        new = lambda: [torch.empty((B, sdim), dtype=torch.float32, device=vs[0].device) for _ in range(m)]
+        hs, zs, gms, os_ = new(), new(), new(), new()
+        io = XFusionFn._io(m, vs, w, hs, zs, gms, os_)
+        check(lib().mmf_xreduce_forward(C.byref(io), float(p), seed, stream_ptr()), "mmf_xreduce_forward")
+        We1, be1, We2, be2 = w[6 * m:6 * m + 4]
+        B, dim = os_[0].shape
+        kr = torch.empty((B, (dim + 1) ** m), dtype=torch.float32, device=vs[0].device)
+        arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
+        check(lib().mmf_kron_forward(arr, m, dim, B, float(p), seed, 8, ptr(kr), stream_ptr()), "mmf_kron_forward")
+        e1 = _dense_fwd_raw(kr, We1, be1, "relu", kind, p, seed, 9)
+        cat2 = torch.cat([e1] + vs, dim=1)
+        e2 = _dense_fwd_raw(cat2, We2, be2, "relu", kind, p, seed, 10)
+        ctx.cfg = (m, float(p), seed, kind)
+        ctx.save_for_backward(*vs, *w, *hs, *zs, *gms, *os_, kr, e1, cat2, e2)
+        return e2
+
+    @staticmethod
+    def _io(m, vs, w, hs, zs, gms, os_):
+        io = _lib.XReduceIO(m=m, B=vs[0].shape[0], dim=vs[0].shape[1], sdim=w[0].shape[0])
+        for i in range(m):
+            Wh, bh, Wz, bz, Wo, bo = w[6 * i:6 * i + 6]
+            io.v[i] = ptr(vs[i]); io.Wh[i] = ptr(Wh); io.bh[i] = ptr(bh); io.Wz[i] = ptr(Wz); io.bz[i] = ptr(bz)
+            io.Wo[i] = ptr(Wo); io.bo[i] = ptr(bo)
+            io.h[i] = ptr(hs[i]); io.z[i] = ptr(zs[i]); io.gm[i] = ptr(gms[i]); io.o[i] = ptr(os_[i])
+        return io
+
+    @staticmethod
+    def backward(ctx, g):
+        m, p, seed, kind = ctx.cfg
+        t = list(ctx.saved_tensors)
+        vs, t = t[:m], t[m:]
+        w, t = t[:6 * m + 4], t[6 * m + 4:]
+        hs, zs, gms, os_ = t[:m], t[m:2 * m], t[2 * m:3 * m], t[3 * m:4 * m]
+        kr, e1, cat2, e2 = t[4 * m:4 * m + 4]
+        We1, be1, We2, be2 = w[6 * m:6 * m + 4]
+        g = _f32c(g)
+        d_cat2, dWe2, dbe2 = _dense_bwd_raw(g, e2, cat2, We2, True, "relu", kind, p, seed, 10)
+        H1 = e1.shape[1]
+        d_e1 = d_cat2[:, :H1].contiguous()
+        dim_v = vs[0].shape[1]
+        d_kr, dWe1, dbe1 = _dense_bwd_raw(d_e1, e1, kr, We1, True, "relu", kind, p, seed, 9)
+        B, dim = os_[0].shape
+        d_os = [torch.empty_like(o) for o in os_]
+        arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
+        darr = (C.c_void_p * m)(*[ptr(d) for d in d_os])
+        check(lib().mmf_kron_backward(ptr(d_kr), arr, m, dim, B, p, seed, 8, darr, stream_ptr()), "mmf_kron_backward")
+        io = XFusionFn._io(m, vs, w, hs, zs, gms, os_)
+        dvs = [torch.empty_like(v) for v in vs]
+        grads_w = []
+        for i in range(m):
+            Wh, bh, Wz, bz, Wo, bo = w[6 * i:6 * i + 6]
+            gw = [torch.empty_like(x) for x in (Wh, bh, Wz, bz, Wo, bo)]
+            io.d_o[i] = ptr(d_os[i]); io.dv[i] = ptr(dvs[i])
+            io.dWh[i], io.dbh[i], io.dWz[i], io.dbz[i], io.dWo[i], io.dbo[i] = [ptr(x) for x in gw]
+            grads_w += gw
+        check(lib().mmf_xreduce_backward(C.byref(io), p, seed, stream_ptr()), "mmf_xreduce_backward")
+        for i in range(m):      # skip connection: encoder2 saw the v_i directly
+            dvs[i] += d_cat2[:, H1 + dim_v * i: H1 + dim_v * (i + 1)]
+        return (None, None, None) + tuple(dvs) + tuple(grads_w) + (dWe1, dbe1, dWe2, dbe2)
+
+
+def xfusion(v_list, weights, p=0.0, seed=0):
+    """weights: [Wh_0, bh_0, Wz_0, bz_0, Wo_0, bo_0, ..., We1, be1, We2, be2]."""
+    return XFusionFn.apply(len(v_list), p, seed, *v_list, *weights)
