@@ -81,6 +81,22 @@ int mmf_amil_backward(const mmf_amil_desc* desc, const float* x, void* workspace
                       const mmf_amil_grads* grads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16-storage variant of the same stack (BASELINE config 5: 100k x 1024 bags, HBM-bound).
+ *   x is a bf16 bag [N x L] (raw bits, row-major).  Parameters and returned gradients stay fp32;
+ *   per call the library makes bf16 copies of W1 / Wa / Wb in the workspace, keeps h, a, b, du in
+ *   bf16, multiplies on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, and runs every epilogue
+ *   (bias, ReLU, tanh, sigmoid, dropout, scores, softmax pooling) in fp32.  M and A_raw are fp32.
+ *   Same desc, same dropout masks as the fp32 entry points.  Needs L % 64 == 0, H % 256 == 0.
+ *   grads->dx must be NULL (the bag is a leaf).
+ * ------------------------------------------------------------------------------------------- */
+size_t mmf_amil_bf16_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated);
+int mmf_amil_bf16_forward(const mmf_amil_desc* desc, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                          float* M, float* A_raw, void* stream);
+int mmf_amil_bf16_backward(const mmf_amil_desc* desc, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                           const float* M, const float* A_raw, const float* dM, const float* gA,
+                           const mmf_amil_grads* grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense layer on MFMA:  y = dropout(act(concat_k(x_0..x_{nseg-1}) . W^T + bias))
  *   replaces torch.cat + nn.Linear of model_attention_mil_radio.py:80-82 (reduce_dim; the modality
  *   bags are never concatenated in memory) and the instance projections generally.

@@ -1,0 +1,878 @@
+// bf16-storage attention-MIL kernels for MI355X (gfx950): v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// Same decomposition as the fp32 path (mmf_amil_fwd.hip / mmf_amil_bwd.hip) -- K-lin, K-gate, K-pool, K-dh (K-prep
+// fused), K-tn, K-red -- and the same formulas; what changes is the storage type of the bag
+// and of every saved activation (mmf_bf16.h lists the rounding points), which halves the HBM traffic of a path that,
+// at bf16 MFMA rates, is bound by HBM and by the per-CU operand delivery rather than by the matrix cores.
+//
+//   NT kernels (K-lin, K-gate, K-dh) reuse the fp32 GEMM core: a 64-bf16 chunk row is the same 128 bytes as a
+//   32-float row, so the loaders, the padded LDS image and the pipeline are shared and only the MFMA differs
+//   (Tile<..., BF16 = true>).
+//   K-tn contracts over the instance index, which is the strided dimension of both operands.  The chunk is staged
+//   as it lies in HBM ([instance][column], 16-byte copies) and the MFMA fragments are read with
+//   ds_read_b64_tr_b16, gfx950's transposing LDS read: per 16-lane group it takes a 4-instance x 16-column block
+//   and hands every lane ONE column's 4 instances, i.e. 4 consecutive k of that lane's output row.
+#include <cstdlib>
+
+#include "mmf_gemm_core.h"
+#include "mmf_bf16.h"
+
+namespace mmf {
+
+template <class T, class P>
+static int launch_tiled_b(const char* name, void (*kern)(P), const P& p, int grid, int lds_bytes, hipStream_t st) {
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return e;
+  ProfScope ps(name, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), lds_bytes, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// =============================================================================================
+// K-cvt : fp32 parameters -> bf16 copies (optionally transposed), a few hundred thousand elements
+// =============================================================================================
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
+  const int b = blockIdx.x;
+  int si = 0;
+  for (int i = 1; i < p.nseg; ++i)
+    if (b >= p.seg[i].block_begin) si = i;
+  const CvtSeg& s = p.seg[si];
+  const int e = (b - s.block_begin) * 256 + threadIdx.x;
+  if (e >= s.rows * s.cols) return;
+  const int r = e / s.cols, c = e - r * s.cols;
+  const bf16_t v = f2bf(s.src[e]);
+  if (s.transpose) s.dst[(size_t)c * s.dst_ld + s.c0 + r] = v;
+  else s.dst[(size_t)r * s.dst_ld + s.c0 + c] = v;
+}
+
+int launch_cvt_bf16(CvtParams p, hipStream_t st) {
+  int blocks = 0;
+  for (int i = 0; i < p.nseg; ++i) {
+    p.seg[i].block_begin = blocks;
+    blocks += (p.seg[i].rows * p.seg[i].cols + 255) / 256;
+  }
+  if (blocks == 0) return MMF_OK;
+  { ProfScope ps("cvt_bf16_kernel", st); hipLaunchKernelGGL(cvt_bf16_kernel, dim3(blocks), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// row tiles: 256 x 256 (8 waves as 2 x 4, wave tile 128 x 64) or 128 x 256; one workgroup per CU either way
+using TileB256 = Tile<256, 256, 2, 4, true, true, 4, true>;
+using TileB128 = Tile<128, 256, 2, 4, true, true, 4, true>;
+
+// 256-row tiles unless 128-row tiles fill the 256 CUs in fewer (half-length) rounds
+static inline int pick_bm(int64_t rows, int ntn) {
+  static const int env = getenv("MMF_BF16_BM") ? atoi(getenv("MMF_BF16_BM")) : 0;   // tuning override
+  if (env == 128 || env == 256) return env;
+  const int64_t t256 = ((rows + 255) / 256) * ntn, t128 = ((rows + 127) / 128) * ntn;
+  const double c256 = (double)((t256 + 255) / 256) * 2.15, c128 = (double)((t128 + 255) / 256) * 1.15;
+  return c128 < c256 ? 128 : 256;
+}
+
+// =============================================================================================
+// K-lin : h = bf16(drop(relu(x.W1^T + b1)))
+// =============================================================================================
+template <class T>
+__global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, col0 = nt * T::BN;
+  LoadK<T::BM, T::NT> la;
+  la.init(reinterpret_cast<const float*>(p.x), p.K / 2, row0, (int)p.M);
+  LoadK<T::BN, T::NT> lb;
+  lb.init(reinterpret_cast<const float*>(p.w), p.K / 2, col0, p.N);
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, p.K / 64, lds, acc);
+
+  const uint32_t thr = drop_threshold(p.drop_p);
+  const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const uint32_t dkey = p.drop_key + (p.seed_dev ? *p.seed_dev : 0u);
+  float4 bias4[T::NB];
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb) {
+    const int col = col0 + epilogue_col<T>(nb);
+    bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
+  }
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = col0 + c;
+    if (col >= p.N) return;
+    const float4 b4 = bias4[nb];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = row0 + r + 8 * t;
+      if (row >= p.M) continue;
+      float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
+      const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[e] = fmaxf(y[e], 0.f);
+        if (p.drop_p > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
+      }
+      *reinterpret_cast<uint2*>(p.y + (size_t)row * p.N + col) = pack4(y[0], y[1], y[2], y[3]);
+    }
+  });
+}
+
+int launch_linear_bf16(LinearBfParams p, hipStream_t st) {
+  if (p.K % 64 != 0 || p.N % 256 != 0) return MMF_ERR_SHAPE;
+  if (p.M <= 0) return MMF_OK;
+  p.nt_count = p.N / 256;
+  if (pick_bm(p.M, p.nt_count) == 128) {
+    using T = TileB128;
+    p.mt_count = (int)((p.M + T::BM - 1) / T::BM);
+    return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
+  }
+  using T = TileB256;
+  p.mt_count = (int)((p.M + T::BM - 1) / T::BM);
+  return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
+}
+
+// =============================================================================================
+// K-gate : a, b saved as bf16; per-row partial scores from the unrounded epilogue values
+// =============================================================================================
+// B-operand rows alternate 32-row blocks (a, b) of the same 32 attention dims (the fp32 kernel's layout): a wave's
+// nb = 2t, 2t+1 accumulators are the tanh and the sigmoid pre-activation of the same (instance, d).
+template <int ROWS, int NT, bool GATED>
+struct LoadGateWB {
+  using Map = KMap<ROWS, NT>;
+  rsrc_t ra, rb;
+  int tid;
+  int which[Map::NV];
+  unsigned voff[Map::NV];
+  float4 r[Map::NV];
+  __device__ inline void init(const bf16_t* wa, const bf16_t* wb, int H, int D, int d0) {
+    tid = threadIdx.x;
+    ra = make_rsrc(wa, (unsigned)D * (unsigned)H * 2u);
+    rb = make_rsrc(GATED ? wb : wa, (unsigned)D * (unsigned)H * 2u);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      const int j = Map::row(tid, i);
+      int w, d;
+      if (!GATED) { w = 0; d = d0 + j; }
+      else { w = (j >> 5) & 1; d = d0 + (j >> 6) * 32 + (j & 31); }
+      which[i] = __builtin_amdgcn_readfirstlane(w);
+      voff[i] = (Map::valid(tid, i) && d < D) ? ((unsigned)d * (unsigned)H + 8u * Map::c4(tid, i)) * 2u : OOB;
+    }
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = (unsigned)kt * 128u;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(which[i] ? rb : ra, voff[i], soff);
+  }
+  __device__ inline void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
+  }
+};
+
+template <class T, bool GATED>
+__global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr int DT = GATED ? T::BN / 2 : T::BN;
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, d0 = nt * DT;
+  LoadK<T::BM, T::NT> la;
+  la.init(reinterpret_cast<const float*>(p.h), p.H / 2, row0, (int)p.N);
+  LoadGateWB<T::BN, T::NT, GATED> lb;
+  lb.init(p.Wa, p.Wb, p.H, p.D, d0);
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, p.H / 64, lds, acc);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int rr = lane >> 3, c4 = lane & 7;
+  const uint32_t thr = drop_threshold(p.drop_p);
+  const bool drop = p.drop_p > 0.f;
+  const float dscale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const uint32_t sdev = p.seed_dev ? *p.seed_dev : 0u;
+  const uint32_t key_a = p.key_a + sdev, key_b = p.key_b + sdev;
+  float* blk = lds + wave * (32 * EPI_STRIDE);
+  float* sred = lds + (T::NT / 64) * (32 * EPI_STRIDE);   // [WN][BM] row partials
+
+  constexpr int NPAIR = GATED ? T::NB / 2 : T::NB;
+  float4 ba_r[NPAIR], bb_r[NPAIR], wc_r[NPAIR];
+#pragma unroll
+  for (int t = 0; t < NPAIR; ++t) {
+    const int d = d0 + (wn * NPAIR + t) * 32 + 4 * c4;
+    const bool dok = d < p.D;
+    ba_r[t] = dok ? ld4(p.ba + d) : zero4();
+    bb_r[t] = (GATED && dok) ? ld4(p.bb + d) : zero4();
+    wc_r[t] = dok ? ld4(p.Wc + d) : zero4();
+  }
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb) {
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NPAIR; ++t) {
+      const int d = d0 + (wn * NPAIR + t) * 32 + 4 * c4;
+      const bool dok = d < p.D;
+      float4 va[4], vb[4];
+      transpose_block(acc[mb][GATED ? 2 * t : t], blk, lane, va);
+      if constexpr (GATED) transpose_block(acc[mb][2 * t + 1], blk, lane, vb);
+      const float4 ba4 = ba_r[t], bb4 = bb_r[t], wc4 = wc_r[t];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + (wm * T::MB + mb) * 32 + rr + 8 * q;
+        float av[4] = {fast_tanh(va[q].x + ba4.x), fast_tanh(va[q].y + ba4.y), fast_tanh(va[q].z + ba4.z), fast_tanh(va[q].w + ba4.w)};
+        float bv[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (GATED) {
+          bv[0] = fast_sigmoid(vb[q].x + bb4.x); bv[1] = fast_sigmoid(vb[q].y + bb4.y);
+          bv[2] = fast_sigmoid(vb[q].z + bb4.z); bv[3] = fast_sigmoid(vb[q].w + bb4.w);
+        }
+        if (row < p.N && dok) {
+          const size_t o = (size_t)row * p.D + d;
+          *reinterpret_cast<uint2*>(p.a + o) = pack4(av[0], av[1], av[2], av[3]);
+          if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pack4(bv[0], bv[1], bv[2], bv[3]);
+          const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
+          const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float ad = av[e], bd = bv[e];
+            if (drop) {
+              ad = keep(key_a, idx + e, thr) ? ad * dscale : 0.f;
+              if constexpr (GATED) bd = keep(key_b, idx + e, thr) ? bd * dscale : 0.f;
+            }
+            rowsum[q] += ad * bd * wc[e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = rowsum[q];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      if (c4 == 0) sred[wn * T::BM + (wm * T::MB + mb) * 32 + rr + 8 * q] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < T::BM; i += T::NT) {
+    const int row = row0 + i;
+    if (row < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < T::WN; ++w) s += sred[w * T::BM + i];
+      p.s_part[(size_t)nt * p.N + row] = s;
+    }
+  }
+}
+
+int gate_parts_bf16(int D, int gated) { return gated ? (D + 127) / 128 : (D + 255) / 256; }
+
+template <class T>
+static int launch_gate_bf16_t(GateBfParams p, hipStream_t st) {
+  p.mt_count = (int)((p.N + T::BM - 1) / T::BM);
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  return p.gated ? launch_tiled_b<T>("gate_bf16_kernel", gate_bf16_kernel<T, true>, p, grid, T::LDS_BYTES, st)
+                 : launch_tiled_b<T>("gate_bf16_kernel", gate_bf16_kernel<T, false>, p, grid, T::LDS_BYTES, st);
+}
+
+int launch_gate_bf16(GateBfParams p, hipStream_t st) {
+  if (p.H % 64 != 0 || p.D % 32 != 0) return MMF_ERR_SHAPE;
+  if (p.N <= 0) return MMF_OK;
+  p.nt_count = gate_parts_bf16(p.D, p.gated);
+  return pick_bm(p.N, p.nt_count) == 128 ? launch_gate_bf16_t<TileB128>(p, st) : launch_gate_bf16_t<TileB256>(p, st);
+}
+
+// =============================================================================================
+// K-pool : scores + per-group online-softmax partials over the bf16 h
+// =============================================================================================
+constexpr int POOLB_MAX_ROWS = 8192;
+
+__global__ __launch_bounds__(256) void pool_partial_bf16_kernel(PoolBfParams pb) {
+  __shared__ float s_lds[POOLB_MAX_ROWS];
+  __shared__ float red[256];
+  __shared__ __align__(16) float vred[2048];   // RG * VPR == 256 slots of 8 floats
+  const PoolParams& p = pb.base;
+  const int tid = threadIdx.x, g = blockIdx.x;
+  const int64_t r0 = (int64_t)g * p.rows_per_group;
+  const int64_t r1 = r0 + p.rows_per_group < p.N ? r0 + p.rows_per_group : p.N;
+  const int nrows = r1 > r0 ? (int)(r1 - r0) : 0;
+  const float bc = p.bc ? p.bc[0] : 0.f;
+
+  float lmax = -INFINITY;
+  for (int i = tid; i < nrows; i += 256) {
+    float s = bc;
+    for (int t = 0; t < p.n_parts; ++t) s += p.s_part[(size_t)t * p.N + r0 + i];
+    p.A_raw[r0 + i] = s;
+    s_lds[i] = s;
+    lmax = fmaxf(lmax, s);
+  }
+  lmax = wave_max(lmax);
+  if ((tid & 63) == 0) red[tid >> 6] = lmax;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+
+  const int VPR = p.H / 8;          // 16-byte vectors per row: 32 (H=256), 64 (H=512), 128 (H=1024)
+  const int RG = 256 / VPR;
+  const int cv = tid % VPR, rg = tid / VPR;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+  for (int i = rg; i < nrows; i += RG) {
+    const float e = __expf(s_lds[i] - m);
+    const float4 raw = ld4(reinterpret_cast<const float*>(pb.h + (size_t)(r0 + i) * p.H + 8 * cv));
+    float hv[8];
+    unpack8(raw, hv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += e * hv[k];
+    if (cv == 0) lsum += e;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vred[(rg * VPR + cv) * 8 + k] = v[k];
+  if (cv == 0) red[rg] = lsum;
+  __syncthreads();
+  float* out = p.partials + (size_t)g * (2 + p.H);
+  for (int c = tid; c < p.H; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < RG; ++q) s += vred[q * p.H + c];      // slot (q, cv) covers columns 8cv .. 8cv+7
+    out[2 + c] = s;
+  }
+  if (tid == 0) {
+    float l = 0.f;
+    for (int q = 0; q < RG; ++q) l += red[q];
+    out[0] = nrows > 0 ? m : -INFINITY;
+    out[1] = l;
+  }
+}
+
+int launch_pool_bf16(PoolBfParams pb, hipStream_t st) {
+  PoolParams& p = pb.base;
+  if (p.H != 256 && p.H != 512 && p.H != 1024) return MMF_ERR_SHAPE;
+  p.n_groups = pool_groups(p.N);
+  p.rows_per_group = (int)((p.N + p.n_groups - 1) / p.n_groups);
+  if (p.rows_per_group > POOLB_MAX_ROWS) return MMF_ERR_SHAPE;
+  { ProfScope ps("pool_partial_bf16_kernel", st); hipLaunchKernelGGL(pool_partial_bf16_kernel, dim3(p.n_groups), dim3(256), 0, st, pb); }
+  if (hipGetLastError() != hipSuccess) return MMF_ERR_LAUNCH;
+  return launch_pool_merge(p, st);
+}
+
+// =============================================================================================
+// K-dh : du = bf16((dP.Wab + p dM) . relu'(h) . scale_h),  dP built on the fly, K-prep fused
+// =============================================================================================
+__device__ inline GateBwdCtx gate_ctx(const GateBwdBf& g) {
+  GateBwdCtx c{};
+  c.D = g.D; c.gated = g.gated; c.drop_p = g.drop_p;
+  const uint32_t sd = g.seed_dev ? *g.seed_dev : 0u;
+  c.key_a = g.key_a + sd; c.key_b = g.key_b + sd; c.seed_dev = nullptr;
+  return c;
+}
+
+template <int ROWS, int NT>
+struct LoadPB {    // A[i][k] = dP (k = [d pre-tanh | d pre-sigmoid]), k-contiguous image, 64 k per chunk
+  using Map = KMap<ROWS, NT>;
+  GateBwdCtx gc;
+  rsrc_t ra, rb, rwc;
+  int row0, tid, part, d0, D;
+  uint32_t thr;
+  float dscale;
+  unsigned voff[Map::NV];
+  float dsr[Map::NV];
+  float4 ra4[Map::NV], rb4[Map::NV], wc_lo, wc_hi;
+  __device__ inline void init_lds(const GateBwdBf& g, int row0_, int nrows, const float* ds_lds) {
+    gc = gate_ctx(g); D = g.D; row0 = row0_; tid = threadIdx.x;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const unsigned bytes = (unsigned)nrows * (unsigned)D * 2u;
+    ra = make_rsrc(g.a, bytes);
+    rb = make_rsrc(g.gated ? g.b : g.a, bytes);
+    rwc = make_rsrc(g.Wc, (unsigned)D * 4u);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      const int rl = Map::row(tid, i), rr = row0 + rl;
+      const bool ok = Map::valid(tid, i) && rr < nrows;
+      voff[i] = ok ? ((unsigned)rr * (unsigned)D + 8u * Map::c4(tid, i)) * 2u : OOB;
+      dsr[i] = ok ? ds_lds[rl] : 0.f;
+    }
+  }
+  __device__ inline void load(int kt) {
+    const int nka = D / 64;
+    part = kt >= nka ? 1 : 0;
+    d0 = (kt - part * nka) * 64;
+    wc_lo = bld4(rwc, 32u * (tid & 7), (unsigned)d0 * 4u);
+    wc_hi = bld4(rwc, 32u * (tid & 7) + 16u, (unsigned)d0 * 4u);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      ra4[i] = bld4(ra, voff[i], (unsigned)d0 * 2u);
+      rb4[i] = bld4(rb, voff[i], (unsigned)d0 * 2u);
+    }
+  }
+  __device__ inline void store(float* lds) const {
+    const int c = d0 + 8 * (tid & 7);
+    const float wc[8] = {wc_lo.x, wc_lo.y, wc_lo.z, wc_lo.w, wc_hi.x, wc_hi.y, wc_hi.z, wc_hi.w};
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      if (!Map::valid(tid, i)) continue;
+      const int rr = row0 + Map::row(tid, i);
+      const uint32_t idx = (uint32_t)rr * (uint32_t)D + (uint32_t)c;
+      float av[8], bv[8], o[8], dummy;
+      unpack8(ra4[i], av);
+      unpack8(rb4[i], bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = gate_dp(gc, part, av[e], bv[e], wc[e], dsr[i], idx + e, thr, dscale, dummy);
+      st4(lds + Map::lds(tid, i), pack8(o));
+    }
+  }
+};
+
+template <class T>
+__global__ __launch_bounds__(T::NT) void dh_bf16_kernel(DhBfParams p) {
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, col0 = nt * T::BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers
+  float* p_l = ds_l + T::BM;
+  {
+    // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
+    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
+    float dmm = 0.f;
+    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
+    dmm = wave_sum(dmm);
+    float dm_l[2][8];                              // dM of this lane's columns 8 lane + 512 q (H <= 1024)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = 8 * lane + 512 * q;
+      const float4 lo = c < p.H ? ld4(p.dM + c) : zero4(), hi = c < p.H ? ld4(p.dM + c + 4) : zero4();
+      dm_l[q][0] = lo.x; dm_l[q][1] = lo.y; dm_l[q][2] = lo.z; dm_l[q][3] = lo.w;
+      dm_l[q][4] = hi.x; dm_l[q][5] = hi.y; dm_l[q][6] = hi.z; dm_l[q][7] = hi.w;
+    }
+    float dbc = 0.f;
+    constexpr int NW = T::NT / 64;
+    for (int r0 = wave * 4; r0 < T::BM; r0 += NW * 4) {
+      float g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + r0 + u;
+        const int rc = row < p.N ? row : (int)p.N - 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (8 * lane + 512 * q < p.H) {
+            float hv[8];
+            unpack8(ld4(reinterpret_cast<const float*>(p.h + (size_t)rc * p.H + 8 * lane + 512 * q)), hv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += hv[k] * dm_l[q][k];
+          }
+        g[u] = acc;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = wave_sum(g[u]);
+      if (lane < 4 && r0 + lane < T::BM) {
+        const int row = row0 + r0 + lane;
+        const float gv = lane == 0 ? g[0] : (lane == 1 ? g[1] : (lane == 2 ? g[2] : g[3]));
+        float pi = 0.f, d = 0.f;
+        if (row < p.N) {
+          pi = __expf(p.A_raw[row] - smax) * inv;
+          d = pi * (gv - dmm) + (p.gA ? p.gA[row] : 0.f);
+          if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+        }
+        ds_l[r0 + lane] = d;
+        p_l[r0 + lane] = pi;
+        dbc += d;
+      }
+    }
+    dbc = wave_sum(dbc);
+    float* red = p_l + T::BM;
+    if (lane == 0) red[wave] = dbc;
+    __syncthreads();
+    if (tid == 0 && nt == 0) {
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w) s += red[w];
+      p.dbc_part[mt] = s;
+    }
+  }
+  const int mstk = p.g.gated ? 2 * p.g.D : p.g.D;
+  LoadPB<T::BM, T::NT> la;
+  la.init_lds(p.g, row0, (int)p.N, ds_l);
+  LoadK<T::BN, T::NT> lb;
+  lb.init(reinterpret_cast<const float*>(p.WabT), mstk / 2, col0, p.H);
+  f32x16 acc[T::MB][T::NB];
+  gemm_mainloop<T>(la, lb, mstk / 64, lds, acc);
+  float4 dm4[T::NB];
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb) {
+    const int col = col0 + epilogue_col<T>(nb);
+    dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
+  }
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = col0 + c;
+    if (col >= p.H) return;
+    uint2 hraw[4];
+    float pi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {             // all loads first ...
+      const int row = row0 + r + 8 * t;
+      const int rc = row < p.N ? row : (int)p.N - 1;
+      hraw[t] = *reinterpret_cast<const uint2*>(p.h + (size_t)rc * p.H + col);
+      pi[t] = p_l[r + 8 * t];
+    }
+    const float4 dm = dm4[nb];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {             // ... then the stores
+      const int row = row0 + r + 8 * t;
+      if (row >= p.N) continue;
+      float h0, h1, h2, h3;
+      unpack2(hraw[t].x, h0, h1);
+      unpack2(hraw[t].y, h2, h3);
+      const float d0 = h0 > 0.f ? (v[t].x + pi[t] * dm.x) * p.scale_h : 0.f;
+      const float d1 = h1 > 0.f ? (v[t].y + pi[t] * dm.y) * p.scale_h : 0.f;
+      const float d2 = h2 > 0.f ? (v[t].z + pi[t] * dm.z) * p.scale_h : 0.f;
+      const float d3 = h3 > 0.f ? (v[t].w + pi[t] * dm.w) * p.scale_h : 0.f;
+      *reinterpret_cast<uint2*>(p.du + (size_t)row * p.H + col) = pack4(d0, d1, d2, d3);
+    }
+  });
+}
+
+int dh_bf16_row_tiles(int64_t N) { return (int)((N + 127) / 128); }   // upper bound of mt_count (128-row tiles)
+int dh_bf16_tiles_used(int64_t N, int ntn) { const int bm = pick_bm(N, ntn); return (int)((N + bm - 1) / bm); }
+
+template <class T>
+static int launch_dh_bf16_t(DhBfParams p, hipStream_t st) {
+  p.mt_count = (int)((p.N + T::BM - 1) / T::BM);
+  const int bytes = T::LDS_BYTES + (2 * T::BM + 16) * 4;
+  return launch_tiled_b<T>("dh_bf16_kernel", dh_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), bytes, st);
+}
+
+int launch_dh_bf16(DhBfParams p, hipStream_t st) {
+  if (p.g.D % 64 != 0 || p.H % 256 != 0 || p.H > 1024) return MMF_ERR_SHAPE;
+  if (p.N <= 0) return MMF_OK;
+  p.nt_count = p.H / 256;
+  return pick_bm(p.N, p.nt_count) == 128 ? launch_dh_bf16_t<TileB128>(p, st) : launch_dh_bf16_t<TileB256>(p, st);
+}
+
+// =============================================================================================
+// K-tn : split-K TN GEMM over bf16 operands, fragments by transposing LDS reads
+// =============================================================================================
+// LDS image of one operand chunk: [TNB_KCH instances][COLS bf16], row pitch COLS*2 + 64 bytes.  A 32-lane half of a
+// ds_read_b64_tr_b16 covers 4 instance rows x 64 contiguous bytes; with pitch = 64 (mod 256) the 4 rows land on the
+// 4 disjoint quarters of the 64 banks, so the read is conflict-free.
+template <int BM_, int BN_>
+struct TileT {
+  static constexpr int BM = BM_, BN = BN_, WM = 2, WN = 4, NT = 512;
+  static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
+  static constexpr int A_PITCH = BM * 2 + 64, B_PITCH = BN * 2 + 64;
+  static constexpr int A_BYTES = TNB_KCH * A_PITCH, B_BYTES = TNB_KCH * B_PITCH;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static_assert(A_PITCH % 256 == 64 && B_PITCH % 256 == 64, "pitch must be 64 mod 256 for conflict-free transposed reads");
+};
+
+template <int COLS, int NT>
+struct TMap {    // [TNB_KCH][COLS] image in 16-byte pieces; a thread owns the same piece (8 columns) in every slot
+  static constexpr int PPR = COLS / 8;
+  static constexpr int NV = TNB_KCH * PPR / NT;
+  static_assert(NT % PPR == 0 && (TNB_KCH * PPR) % NT == 0, "piece ownership must be slot-invariant");
+  __device__ static inline int krow(int tid, int i) { return (tid + i * NT) / PPR; }
+  __device__ static inline int piece(int tid) { return tid % PPR; }
+};
+
+template <int COLS, int NT, int PITCH>
+struct LoadTPlain {
+  using Map = TMap<COLS, NT>;
+  rsrc_t rs;
+  unsigned ldb, kbase_b;
+  int tid;
+  bool do_sum;
+  unsigned voff[Map::NV];
+  float4 r[Map::NV];
+  float cs[8];
+  __device__ inline void init(const bf16_t* s, int ld, int col0, int ncols, int kbase, int kmax, bool do_sum_) {
+    tid = threadIdx.x; do_sum = do_sum_;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    rs = make_rsrc(s, (unsigned)(kmax > 0 ? kmax : 0) * (unsigned)ld * 2u);
+    ldb = (unsigned)ld * 2u;
+    kbase_b = (unsigned)kbase * ldb;
+    const int c = col0 + 8 * Map::piece(tid);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      voff[i] = c < ncols ? (unsigned)Map::krow(tid, i) * ldb + (unsigned)c * 2u : OOB;
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = kbase_b + (unsigned)(kt * TNB_KCH) * ldb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) r[i] = bld4(rs, voff[i], soff);
+  }
+  __device__ inline void store(char* lds) {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      *reinterpret_cast<float4*>(lds + Map::krow(tid, i) * PITCH + 16 * Map::piece(tid)) = r[i];
+      if (do_sum) {
+        float v[8];
+        unpack8(r[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += v[e];
+      }
+    }
+  }
+};
+
+// A[k = instance][m] = dP of DT attention dims d0 .. d0+DT-1: gated, image columns [0, DT) = d pre-tanh and
+// [DT, 2 DT) = d pre-sigmoid of the same dims (a, b, ds loaded once for both); ungated, DT = ROWS.
+template <int ROWS, int NT, int PITCH, bool GATED>
+struct LoadTGate {
+  static constexpr int DT = GATED ? ROWS / 2 : ROWS;
+  using Map = TMap<DT, NT>;
+  GateBwdCtx gc;
+  rsrc_t ra, rb, rds;
+  int d0, kbase, tid, kt_loaded, D;
+  bool do_sum;
+  uint32_t thr;
+  float dscale;
+  unsigned db;
+  unsigned voff[Map::NV], voff_ds[Map::NV];
+  float4 ra4[Map::NV], rb4[Map::NV];
+  float wc[8], dsr[Map::NV];
+  float cs_a[8], cs_b[8], cs2[8];
+  __device__ inline void init(const GateBwdBf& g, int d0_, int kbase_, int kmax, bool do_sum_) {
+    gc = gate_ctx(g); gc.gated = GATED ? 1 : 0;
+    D = g.D; d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs_a[e] = 0.f; cs_b[e] = 0.f; cs2[e] = 0.f; }
+    db = (unsigned)D * 2u;
+    const unsigned rows = (unsigned)(kmax > 0 ? kmax : 0);
+    ra = make_rsrc(g.a, rows * db);
+    rb = make_rsrc(GATED ? g.b : g.a, rows * db);
+    rds = make_rsrc(g.ds, rows * 4u);
+    const int c = d0 + 8 * Map::piece(tid);
+    const bool ok = c < D;
+    const rsrc_t rwc = make_rsrc(g.Wc, (unsigned)D * 4u);
+    const float4 lo = bld4(rwc, ok ? (unsigned)c * 4u : OOB, 0), hi = bld4(rwc, ok ? (unsigned)c * 4u + 16u : OOB, 0);
+    wc[0] = lo.x; wc[1] = lo.y; wc[2] = lo.z; wc[3] = lo.w; wc[4] = hi.x; wc[5] = hi.y; wc[6] = hi.z; wc[7] = hi.w;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      voff[i] = ok ? (unsigned)Map::krow(tid, i) * db + (unsigned)c * 2u : OOB;
+      voff_ds[i] = ok ? (unsigned)Map::krow(tid, i) * 4u : OOB;
+    }
+    kt_loaded = 0;
+  }
+  __device__ inline void load(int kt) {
+    kt_loaded = kt;
+    const unsigned k0 = (unsigned)(kbase + kt * TNB_KCH);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      ra4[i] = bld4(ra, voff[i], k0 * db);
+      if (GATED) rb4[i] = bld4(rb, voff[i], k0 * db);
+      dsr[i] = bld1(rds, voff_ds[i], k0 * 4u);     // 0 beyond the split's last instance => dP = 0 there
+    }
+  }
+  __device__ inline void store(char* lds) {
+    const int c = d0 + 8 * Map::piece(tid);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      const int k = kbase + kt_loaded * TNB_KCH + Map::krow(tid, i);
+      const uint32_t idx = (uint32_t)k * (uint32_t)D + (uint32_t)c;
+      const float dsv = dsr[i];
+      float av[8], bv[8], oa[8], ob[8], w[8];
+      unpack8(ra4[i], av);
+      if (GATED) unpack8(rb4[i], bv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        oa[e] = gate_dp(gc, 0, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
+        ob[e] = GATED ? gate_dp(gc, 1, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
+      }
+      // the column sums (bias grads) are taken over the ROUNDED operand, i.e. exactly what the MFMA contracts
+      const float4 pa = pack8(oa);
+      char* dst = lds + Map::krow(tid, i) * PITCH + 16 * Map::piece(tid);
+      *reinterpret_cast<float4*>(dst) = pa;
+      float4 pb4 = zero4();
+      if (GATED) { pb4 = pack8(ob); *reinterpret_cast<float4*>(dst + DT * 2) = pb4; }
+      if (do_sum) {
+        float ra_[8], rb_[8];
+        unpack8(pa, ra_);
+        unpack8(pb4, rb_);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs_a[e] += ra_[e]; cs_b[e] += rb_[e]; cs2[e] += dsv * w[e]; }
+      }
+    }
+  }
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// one 32x32x16 operand (this lane: output row/column = block column 16 (g&1) + i, k = 8 (g>>1) .. +7) from two
+// transposed reads 4 instance rows apart; `p` already holds the lane part of the address
+template <int PITCH>
+__device__ inline bf16x8 tr_frag(const char* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * PITCH));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class T>
+__device__ inline void tn_compute_chunk(const char* As, const char* Bs, f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int kq = 8 * (g >> 1) + (i >> 2);            // instance row (within a 16-instance step) this lane addresses
+  const int cq = 16 * (g & 1) + 4 * (i & 3);         // first of the 4 columns this lane addresses
+  const char* a0 = As + kq * T::A_PITCH + (wm * T::MB * 32 + cq) * 2;
+  const char* b0 = Bs + kq * T::B_PITCH + (wn * T::NB * 32 + cq) * 2;
+#pragma unroll
+  for (int q = 0; q < TNB_KCH / 16; ++q) {
+    bf16x8 fa[T::MB], fb[T::NB];
+#pragma unroll
+    for (int mb = 0; mb < T::MB; ++mb) fa[mb] = tr_frag<T::A_PITCH>(a0 + 16 * q * T::A_PITCH + mb * 64);
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) fb[nb] = tr_frag<T::B_PITCH>(b0 + 16 * q * T::B_PITCH + nb * 64);
+#pragma unroll
+    for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < T::NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+  }
+}
+
+template <class T, class LA, class LB>
+__device__ inline void tn_mainloop(LA& la, LB& lb, int nk, char* lds, f32x16 (&acc)[T::MB][T::NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  if (nk <= 0) return;
+  la.load(0);
+  lb.load(0);
+  la.store(lds);
+  lb.store(lds + T::A_BYTES);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = lds + (kt & 1) * T::STAGE_BYTES;
+    char* nxt = lds + ((kt + 1) & 1) * T::STAGE_BYTES;
+    const bool more = kt + 1 < nk;
+    if (more) { la.load(kt + 1); lb.load(kt + 1); }
+    tn_compute_chunk<T>(cur, cur + T::A_BYTES, acc, wm, wn, lane);
+    if (more) { la.store(nxt); lb.store(nxt + T::A_BYTES); }
+    __syncthreads();
+  }
+}
+
+// reduce per-thread 8-column sums over the NT/(COLS/8) threads that own the same 8 of COLS columns
+template <int COLS, int NT>
+__device__ inline void colsum8_reduce_store(float* lds, const float (&v)[8], float* dst, int col0, int ncols) {
+  constexpr int PPR = COLS / 8, GROUPS = NT / PPR;
+  const int tid = threadIdx.x;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 8; ++e) lds[(tid / PPR) * COLS + 8 * (tid % PPR) + e] = v[e];
+  __syncthreads();
+  if (tid < COLS) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < GROUPS; ++q) s += lds[q * COLS + tid];
+    if (col0 + tid < ncols) dst[col0 + tid] = s;
+  }
+}
+
+template <class T, class RowMap>
+__device__ inline void tnb_store(const TnBfProblem& q, int split, int tn, f32x16 (&acc)[T::MB][T::NB], float* lds, RowMap&& rowmap) {
+  float* out = q.out + (size_t)split * q.split_stride;
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    const int col = tn * T::BN + c;
+    if (col >= q.Ncols) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = rowmap(r + 8 * t);
+      if (row >= 0) st4(out + (size_t)row * q.ldc + col, v[t]);
+    }
+  });
+}
+
+template <class T, bool GATED>
+__device__ inline void tnb_gate_tile(const TnBfParams& p, const TnBfProblem& q, LoadTPlain<T::BN, T::NT, T::B_PITCH>& lb,
+                                     int split, int tm, int tn, int kbase, int kmax, int nk, bool do_sum, char* lds) {
+  using LA = LoadTGate<T::BM, T::NT, T::A_PITCH, GATED>;
+  constexpr int DT = LA::DT;
+  const int D = p.g.D, d0 = tm * DT;
+  LA la;
+  la.init(p.g, d0, kbase, kmax, do_sum);
+  f32x16 acc[T::MB][T::NB];
+  tn_mainloop<T>(la, lb, nk, lds, acc);
+  float* fl = reinterpret_cast<float*>(lds);
+  tnb_store<T>(q, split, tn, acc, fl, [&](int r) {
+    const int half = r / DT, d = d0 + r - half * DT;
+    return d < D ? half * D + d : -1;
+  });
+  if (do_sum) {
+    float* cs = q.colsum + (size_t)split * q.colsum_stride;
+    colsum8_reduce_store<DT, T::NT>(fl, la.cs_a, cs, d0, D);
+    if (GATED) colsum8_reduce_store<DT, T::NT>(fl, la.cs_b, cs + D, d0, D);
+    if (q.colsum2) colsum8_reduce_store<DT, T::NT>(fl, la.cs2, q.colsum2 + (size_t)split * q.colsum2_stride, d0, D);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
+  extern __shared__ __align__(16) char ldsb[];
+  const int b = blockIdx.x;
+  const int split = b / p.total_tiles, tg = b - split * p.total_tiles;
+  int pi = 0;
+  for (int i = 1; i < p.nprob; ++i)
+    if (tg >= p.prob[i].block_begin) pi = i;
+  const TnBfProblem& q = p.prob[pi];
+  const int t = tg - q.block_begin;
+  const int tm = t / q.tiles_n, tn = t - tm * q.tiles_n;
+  const int64_t kb64 = (int64_t)split * p.k_per_split;
+  const int kbase = (int)(kb64 < p.K ? kb64 : p.K);
+  const int kmax = (int)((kb64 + p.k_per_split) < p.K ? (kb64 + p.k_per_split) : p.K);
+  const int nk = (kmax - kbase + TNB_KCH - 1) / TNB_KCH;
+  const bool do_sum = tn == 0 && q.colsum != nullptr;
+
+  LoadTPlain<T::BN, T::NT, T::B_PITCH> lb;
+  lb.init(q.B, q.ldb, tn * T::BN, q.Ncols, kbase, kmax, false);
+  if (q.kind == TN_A_PLAIN) {
+    LoadTPlain<T::BM, T::NT, T::A_PITCH> la;
+    la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
+    f32x16 acc[T::MB][T::NB];
+    tn_mainloop<T>(la, lb, nk, ldsb, acc);
+    float* fl = reinterpret_cast<float*>(ldsb);
+    tnb_store<T>(q, split, tn, acc, fl, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
+    if (do_sum) colsum8_reduce_store<T::BM, T::NT>(fl, la.cs, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+  } else if (p.g.gated) {
+    tnb_gate_tile<T, true>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, ldsb);
+  } else {
+    tnb_gate_tile<T, false>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, ldsb);
+  }
+}
+
+int tn_bf16_splits(int64_t K, int total_tiles) {
+  static const int env = getenv("MMF_BF16_TN_SPLITS") ? atoi(getenv("MMF_BF16_TN_SPLITS")) : 0;   // tuning override
+  int splits = 256 / (total_tiles > 0 ? total_tiles : 1);
+  if (env > 0) splits = env;
+  const int64_t max_splits = (K + 255) / 256;
+  if (splits > max_splits) splits = (int)max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+int launch_tn_bf16(TnBfParams p, hipStream_t st) {
+  using T = TileT<TNB_TILE, TNB_TILE>;
+  if (p.k_per_split % TNB_KCH != 0 || p.splits < 1) return MMF_ERR_ARG;
+  int blocks = 0;
+  for (int i = 0; i < p.nprob; ++i) {
+    TnBfProblem& q = p.prob[i];
+    if (q.Ncols % 8 != 0 || q.ldb % 8 != 0 || q.M % 8 != 0) return MMF_ERR_SHAPE;
+    if (q.kind == TN_A_PLAIN && q.lda % 8 != 0) return MMF_ERR_SHAPE;
+    if (q.kind == TN_A_GATE) {
+      const int dt = p.g.gated ? T::BM / 2 : T::BM;
+      q.tiles_m = (p.g.D + dt - 1) / dt;
+    } else {
+      q.tiles_m = (q.M + T::BM - 1) / T::BM;
+    }
+    q.tiles_n = (q.Ncols + T::BN - 1) / T::BN;
+    q.block_begin = blocks;
+    blocks += q.tiles_m * q.tiles_n;
+  }
+  if (blocks == 0) return MMF_OK;
+  p.total_tiles = blocks;
+  return launch_tiled_b<T>("tn_bf16_kernel", tn_bf16_kernel<T>, p, p.splits * blocks, T::LDS_BYTES, st);
+}
+
+}  // namespace mmf

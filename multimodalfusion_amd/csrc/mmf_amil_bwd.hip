@@ -20,22 +20,6 @@
 
 namespace mmf {
 
-__device__ inline float gate_dp(const GateBwdCtx& g, int part, float av, float bv, float wc, float dsv,
-                                uint32_t idx, uint32_t thr, float dscale, float& a_d_b_d) {
-  float ma = 1.f, mb = 1.f;
-  if (g.drop_p > 0.f) {
-    ma = keep(g.key_a, idx, thr) ? dscale : 0.f;
-    if (g.gated) mb = keep(g.key_b, idx, thr) ? dscale : 0.f;
-  }
-  if (g.gated) {
-    a_d_b_d = (av * ma) * (bv * mb);
-    return part == 0 ? dsv * wc * (bv * mb) * ma * (1.f - av * av)
-                     : dsv * wc * (av * ma) * mb * bv * (1.f - bv);
-  }
-  a_d_b_d = av * ma;
-  return dsv * wc * ma * (1.f - av * av);
-}
-
 // =============================================================================================
 // K-prep
 // =============================================================================================

@@ -445,7 +445,11 @@ int launch_pool(PoolParams p, hipStream_t st) {
   p.rows_per_group = (int)((p.N + p.n_groups - 1) / p.n_groups);
   if (p.rows_per_group > POOL_MAX_ROWS) return MMF_ERR_SHAPE;
   { ProfScope ps("pool_partial_kernel", st); hipLaunchKernelGGL(pool_partial_kernel, dim3(p.n_groups), dim3(256), 0, st, p); }
-  if (p.n_groups > MERGE_MAX_GROUPS) return MMF_ERR_SHAPE;
+  return launch_pool_merge(p, st);
+}
+
+int launch_pool_merge(PoolParams p, hipStream_t st) {
+  if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || 1024 % p.H != 0) return MMF_ERR_SHAPE;
   { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(1), dim3(1024), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }

@@ -17,6 +17,7 @@
 #include "mmf_kernels.h"
 #include "mmf_small.h"
 #include "mmf_mlp.h"
+#include "mmf_bf16.h"
 
 namespace mmf {
 
@@ -119,13 +120,71 @@ static int check_desc(const mmf_amil_desc* d) {
   return MMF_OK;
 }
 
+// ---- bf16-storage path (mmf_bf16.h) ----------------------------------------------------------
+struct AmilWsBf {
+  bf16_t *w1, *wab, *wabT, *h, *a, *b, *du;
+  float *s_part, *partials, *stats, *p, *ds, *dbc_part;
+  float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
+  int parts, groups, splits, k_per_split, mstk, dbc_cap;
+  size_t bytes;
+};
+
+static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated) {
+  AmilWsBf w{};
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take_b = [&](size_t nbytes) {
+    char* r = p + off;
+    off += align_up(nbytes, 256);
+    return r;
+  };
+  auto take16 = [&](size_t n) { return reinterpret_cast<bf16_t*>(take_b(n * 2)); };
+  auto take32 = [&](size_t n) { return reinterpret_cast<float*>(take_b(n * 4)); };
+  w.parts = gate_parts_bf16(D, gated);
+  w.groups = pool_groups(N);
+  w.mstk = gated ? 2 * D : D;
+  const int td = TNB_TILE;
+  const int gate_dt = gated ? td / 2 : td;
+  const int tiles = ((H + td - 1) / td) * ((L + td - 1) / td) + ((D + gate_dt - 1) / gate_dt) * ((H + td - 1) / td);
+  w.splits = tn_bf16_splits(N, tiles);
+  const int64_t kps = (N + w.splits - 1) / w.splits;
+  w.k_per_split = (int)((kps + TNB_KCH - 1) / TNB_KCH * TNB_KCH);
+  w.dbc_cap = dh_bf16_row_tiles(N);
+  w.w1 = take16((size_t)H * L);
+  w.wab = take16((size_t)w.mstk * H);
+  w.wabT = take16((size_t)H * w.mstk);
+  w.h = take16((size_t)N * H);
+  w.a = take16((size_t)N * D);
+  w.b = take16(gated ? (size_t)N * D : 0);
+  w.du = take16((size_t)N * H);
+  w.s_part = take32((size_t)w.parts * N);
+  w.partials = take32((size_t)w.groups * (2 + H));
+  w.stats = take32(4);
+  w.p = take32((size_t)N);
+  w.ds = take32((size_t)N);
+  w.dbc_part = take32((size_t)w.dbc_cap);
+  w.slab_w1 = take32((size_t)w.splits * H * L);
+  w.slab_wab = take32((size_t)w.splits * w.mstk * H);
+  w.cs_b1 = take32((size_t)w.splits * H);
+  w.cs_bab = take32((size_t)w.splits * w.mstk);
+  w.cs_wc = take32((size_t)w.splits * D);
+  w.bytes = off;
+  return w;
+}
+
+static int check_desc_bf16(const mmf_amil_desc* d) {
+  if (int e = check_desc(d)) return e;
+  if (d->L % 64 != 0 || d->H % 256 != 0) return MMF_ERR_SHAPE;
+  return MMF_OK;
+}
+
 }  // namespace mmf
 
 using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 2; }
+int mmf_abi_version(void) { return 3; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -245,6 +304,112 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
   seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
   seg(w.dbc_part, g->dbc, 1, dbc_groups, 1);
+  rp.nseg = n;
+  return launch_reduce(rp, st);
+}
+
+size_t mmf_amil_bf16_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated) {
+  if (N < 1) N = 1;
+  return carve_bf16(nullptr, N, L, H, D, gated).bytes;
+}
+
+int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                          float* M, float* A_raw, void* stream) {
+  if (int e = check_desc_bf16(d)) return e;
+  if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
+  if (!aligned16(x) || !aligned16(workspace)) return MMF_ERR_ALIGN;
+  AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  CvtParams cp{};
+  cp.nseg = 0;
+  auto cvt = [&](const float* src, bf16_t* dst, int rows, int cols, int dst_ld, int c0, int transpose) {
+    cp.seg[cp.nseg++] = CvtSeg{src, dst, rows, cols, dst_ld, c0, transpose, 0};
+  };
+  cvt(d->W1, w.w1, d->H, d->L, d->L, 0, 0);
+  cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, 0);
+  cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, 1);
+  if (d->gated) {
+    cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
+    cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, d->D, 1);
+  }
+  if (int e = launch_cvt_bf16(cp, st)) return e;
+
+  LinearBfParams lp{};
+  lp.x = x; lp.w = w.w1; lp.bias = d->b1; lp.y = w.h;
+  lp.M = d->N; lp.N = d->H; lp.K = d->L;
+  lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = g_seed_dev;
+  if (int e = launch_linear_bf16(lp, st)) return e;
+
+  GateBfParams gp{};
+  gp.h = w.h; gp.Wa = w.wab; gp.Wb = d->gated ? w.wab + (size_t)d->D * d->H : nullptr;
+  gp.ba = d->ba; gp.bb = d->bb; gp.Wc = d->Wc;
+  gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
+  gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = g_seed_dev;
+  if (int e = launch_gate_bf16(gp, st)) return e;
+
+  PoolBfParams pb{};
+  PoolParams& pp = pb.base;
+  pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = nullptr; pp.N = d->N; pp.H = d->H;
+  pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
+  pb.h = w.h;
+  return launch_pool_bf16(pb, st);
+}
+
+int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                           const float* M, const float* A_raw, const float* dM, const float* gA,
+                           const mmf_amil_grads* g, void* stream) {
+  if (int e = check_desc_bf16(d)) return e;
+  if (!x || !workspace || !M || !A_raw || !dM || !g) return MMF_ERR_ARG;
+  if (!g->dW1 || !g->db1 || !g->dWa || !g->dba || !g->dWc || !g->dbc) return MMF_ERR_ARG;
+  if (d->gated && (!g->dWb || !g->dbb)) return MMF_ERR_ARG;
+  if (g->dx) return MMF_ERR_ARG;     // the bf16 bag is a leaf: no input gradient on this path
+  if (!aligned16(g->dW1) || !aligned16(g->dWa) || (d->gated && !aligned16(g->dWb))) return MMF_ERR_ALIGN;
+  AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  GateBwdBf gc{};
+  gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = g_seed_dev;
+
+  DhBfParams dp{};
+  dp.g = gc; dp.WabT = w.wabT; dp.dM = dM; dp.h = w.h; dp.du = w.du;
+  dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
+  dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
+  dp.p_out = w.p; dp.ds_out = w.ds; dp.dbc_part = w.dbc_part;
+  if (int e = launch_dh_bf16(dp, st)) return e;
+  const int ntn = d->H / 256;
+
+  TnBfParams tp{};
+  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc;
+  TnBfProblem& q1 = tp.prob[0];   // dW1[H x L] = du^T . x ; db1 = colsum(du)
+  q1.kind = TN_A_PLAIN; q1.A = w.du; q1.lda = d->H; q1.M = d->H;
+  q1.B = x; q1.ldb = d->L; q1.Ncols = d->L;
+  q1.out = w.slab_w1; q1.split_stride = (size_t)d->H * d->L; q1.ldc = d->L;
+  q1.colsum = w.cs_b1; q1.colsum_stride = d->H; q1.colsum2 = nullptr; q1.colsum2_stride = 0;
+  TnBfProblem& q2 = tp.prob[1];   // dWab[(2)D x H] = dP^T . h ; (dba|dbb) = colsum(dP) ; dWc = colsum(ds.a_d.b_d)
+  q2.kind = TN_A_GATE; q2.A = nullptr; q2.lda = 0; q2.M = w.mstk;
+  q2.B = w.h; q2.ldb = d->H; q2.Ncols = d->H;
+  q2.out = w.slab_wab; q2.split_stride = (size_t)w.mstk * d->H; q2.ldc = d->H;
+  q2.colsum = w.cs_bab; q2.colsum_stride = w.mstk; q2.colsum2 = w.cs_wc; q2.colsum2_stride = d->D;
+  if (int e = launch_tn_bf16(tp, st)) return e;
+
+  ReduceParams rp{};
+  int n = 0;
+  auto seg = [&](const float* in, float* out, int len, int nsplit, size_t stride) {
+    rp.seg[n].in = in; rp.seg[n].out = out; rp.seg[n].len = len; rp.seg[n].nsplit = nsplit; rp.seg[n].stride = stride; ++n;
+  };
+  seg(w.slab_w1, g->dW1, d->H * d->L, w.splits, (size_t)d->H * d->L);
+  seg(w.slab_wab, g->dWa, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  if (d->gated) seg(w.slab_wab + (size_t)d->D * d->H, g->dWb, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  seg(w.cs_b1, g->db1, d->H, w.splits, d->H);
+  seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
+  if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
+  seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
+  seg(w.dbc_part, g->dbc, 1, dh_bf16_tiles_used(d->N, ntn), 1);
   rp.nseg = n;
   return launch_reduce(rp, st);
 }

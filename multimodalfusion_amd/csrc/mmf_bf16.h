@@ -1,0 +1,111 @@
+// bf16-storage variant of the attention-MIL path (BASELINE config 5: 100k x 1024 bags, HBM-bound).
+//
+// What is bf16: the bag x, the per-call copies of W1 / Wa / Wb, and every saved or exchanged activation
+// (h, a, b, du, and the on-the-fly dP operand).  What stays fp32: parameters (masters), biases, Wc, the MFMA
+// accumulators, every epilogue (bias, ReLU, tanh, sigmoid, dropout scale, scores, softmax, pooling), the
+// gradients handed back, and the split-K slabs.  Rounding is round-to-nearest-even at exactly these points:
+//   x (given), bf16(W1), bf16(Wa), bf16(Wb);  h = bf16(drop(relu(u)));  a = bf16(tanh), b = bf16(sigmoid) AS SAVED
+//   (the scores use the unrounded a, b of the epilogue registers);  dP = bf16(gate_dp(a, b, ...));  du = bf16(...).
+// The oracle restates the same points (oracle/torch_port.py: bf16 mode).
+#pragma once
+#include "mmf_kernels.h"
+
+namespace mmf {
+
+typedef unsigned short bf16_t;   // storage type (raw bits)
+
+#ifdef __HIPCC__
+__device__ inline float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ inline bf16_t f2bf(float f) {            // round to nearest even (v_cvt_pk_bf16_f32)
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ inline uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ inline void unpack2(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xFFFF0000u);
+}
+__device__ inline void unpack8(const float4& v, float (&o)[8]) {
+  unpack2(__float_as_uint(v.x), o[0], o[1]);
+  unpack2(__float_as_uint(v.y), o[2], o[3]);
+  unpack2(__float_as_uint(v.z), o[4], o[5]);
+  unpack2(__float_as_uint(v.w), o[6], o[7]);
+}
+__device__ inline float4 pack8(const float (&o)[8]) {
+  return make_float4(__uint_as_float(pack2(o[0], o[1])), __uint_as_float(pack2(o[2], o[3])),
+                     __uint_as_float(pack2(o[4], o[5])), __uint_as_float(pack2(o[6], o[7])));
+}
+__device__ inline uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2(a, b), pack2(c, d)); }
+#endif
+
+struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c])   or, transposed, dst[c][c0 + r] = bf16(src[r][c])
+  const float* src; bf16_t* dst;
+  int rows, cols, dst_ld, c0, transpose, block_begin;
+};
+struct CvtParams { CvtSeg seg[6]; int nseg; };
+
+struct LinearBfParams {    // y[M x N] = bf16(drop(relu(x[M x K] . W[N x K]^T + bias)))
+  const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
+  int64_t M; int N, K;
+  float drop_p; uint32_t drop_key; const uint32_t* seed_dev;
+  int mt_count, nt_count;
+};
+
+struct GateBfParams {
+  const bf16_t* h;                       // [N x H]
+  const bf16_t *Wa, *Wb;                 // bf16 copies, [D x H]
+  const float *ba, *bb, *Wc;             // fp32
+  bf16_t *a, *b;                         // [N x D] saved (un-dropped)
+  float* s_part;                         // [nt_count x N]
+  int64_t N; int H, D, gated;
+  float drop_p; uint32_t key_a, key_b; const uint32_t* seed_dev;
+  int mt_count, nt_count;
+};
+
+struct PoolBfParams { PoolParams base; const bf16_t* h; };
+
+struct GateBwdBf {         // what the on-the-fly dP operand needs (bf16 a, b)
+  const bf16_t *a, *b; const float *ds, *Wc;
+  int D, gated; float drop_p; uint32_t key_a, key_b; const uint32_t* seed_dev;
+};
+
+struct DhBfParams {        // du = bf16((dP . Wab + p dM) . relu'(h) . scale_h), K-prep fused
+  GateBwdBf g;
+  const bf16_t* WabT;      // [H x mstk] bf16, row n = column n of [Wa ; Wb]
+  const float* dM; const bf16_t* h; bf16_t* du;
+  int64_t N; int H; float scale_h;
+  const float *A_raw, *stats, *Mpool, *gA;
+  float *p_out, *ds_out, *dbc_part;      // dbc_part[mt_count]
+  int mt_count, nt_count;
+};
+
+struct TnBfProblem {       // C[M x Ncols] = A^T . B over one K split; A, B are bf16 [K x *]
+  int kind;                // TN_A_PLAIN / TN_A_GATE
+  const bf16_t* A; int lda; int M;
+  const bf16_t* B; int ldb; int Ncols;
+  float* out; size_t split_stride; int ldc;
+  float* colsum; size_t colsum_stride;
+  float* colsum2; size_t colsum2_stride;
+  int tiles_m, tiles_n, block_begin;
+};
+struct TnBfParams {
+  TnBfProblem prob[2]; int nprob;
+  int64_t K; int splits, k_per_split, total_tiles;
+  GateBwdBf g;
+};
+
+constexpr int TNB_KCH = 64;   // instances per staged chunk of the bf16 TN kernel
+constexpr int TNB_TILE = 256;
+
+int launch_cvt_bf16(CvtParams p, hipStream_t st);
+int launch_linear_bf16(LinearBfParams p, hipStream_t st);
+int gate_parts_bf16(int D, int gated);
+int launch_gate_bf16(GateBfParams p, hipStream_t st);
+int launch_pool_bf16(PoolBfParams p, hipStream_t st);
+int dh_bf16_row_tiles(int64_t N);              // capacity of dbc_part (upper bound over tile choices)
+int dh_bf16_tiles_used(int64_t N, int ntn);     // dbc partials launch_dh_bf16 writes for this shape
+int launch_dh_bf16(DhBfParams p, hipStream_t st);
+int tn_bf16_splits(int64_t K, int total_tiles);
+int launch_tn_bf16(TnBfParams p, hipStream_t st);
+
+}  // namespace mmf

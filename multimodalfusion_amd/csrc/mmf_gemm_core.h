@@ -31,10 +31,17 @@ constexpr int KSTR = KC + 4;   // padded LDS row stride (floats) of a k-contiguo
 
 // G = k-pairs per fragment group (one MFMA consumes one k-pair).  4 matches a ds_read_b128 of a k-contiguous
 // image; all-m-contiguous tiles may use 2, which halves the (double-buffered) fragment registers.
-template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_, int G_ = 4>
+//
+// BF16 = true: the operands are bf16 and both k-contiguous.  The byte geometry does not change -- a chunk row is
+// still 128 bytes (64 bf16 instead of 32 floats), staged by the same 16-byte copies into the same padded image --
+// so loaders address a bf16 matrix as a float matrix of half the width, and only the MFMA differs: one
+// ds_read_b128 fragment (8 bf16 of one row) feeds ONE v_mfma_f32_32x32x16_bf16 instead of four 32x32x2 fp32 MFMAs.
+template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_, int G_ = 4, bool BF16_ = false>
 struct Tile {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, G = G_;
+  static constexpr bool BF16 = BF16_;
   static_assert(G_ == 4 || (G_ == 2 && !A_KCONTIG_ && !B_KCONTIG_), "G = 2 only for all-m-contiguous tiles");
+  static_assert(!BF16_ || (A_KCONTIG_ && B_KCONTIG_ && G_ == 4), "bf16 tiles are k-contiguous on both sides");
   static constexpr bool A_KCONTIG = A_KCONTIG_, B_KCONTIG = B_KCONTIG_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
@@ -221,8 +228,22 @@ __device__ inline void read_b(const float* __restrict__ Bs, int g, int brow, int
     }
   }
 }
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ inline bf16x8 frag_bf16(const float (&v)[4]) {
+  f32x4 t = {v[0], v[1], v[2], v[3]};
+  return __builtin_bit_cast(bf16x8, t);
+}
+
 template <class T>
 __device__ inline void mfma_part(const FragA<T>& fa, const FragB<T>& fb, int lo, int hi, f32x16 (&acc)[T::MB][T::NB]) {
+  if constexpr (T::BF16) {
+#pragma unroll
+    for (int mb = lo; mb < hi; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < T::NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bf16(fa.v[mb - lo]), frag_bf16(fb.v[nb]), acc[mb][nb], 0, 0, 0);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < T::G; ++j)
 #pragma unroll

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mmf_common.h"
+
 namespace mmf {
 
 enum : int { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_SELU = 4 };
@@ -77,6 +79,24 @@ struct GateBwdCtx {        // what the on-the-fly dP operand needs
   }
 };
 
+// dP[i][k] of one (instance, attention dim): part 0 = d pre-tanh, part 1 = d pre-sigmoid (formulas: mmf_amil_bwd.hip
+// header); a_d_b_d returns the dropped a.b product (dWc needs it).
+__device__ inline float gate_dp(const GateBwdCtx& g, int part, float av, float bv, float wc, float dsv,
+                                uint32_t idx, uint32_t thr, float dscale, float& a_d_b_d) {
+  float ma = 1.f, mb = 1.f;
+  if (g.drop_p > 0.f) {
+    ma = keep(g.key_a, idx, thr) ? dscale : 0.f;
+    if (g.gated) mb = keep(g.key_b, idx, thr) ? dscale : 0.f;
+  }
+  if (g.gated) {
+    a_d_b_d = (av * ma) * (bv * mb);
+    return part == 0 ? dsv * wc * (bv * mb) * ma * (1.f - av * av)
+                     : dsv * wc * (av * ma) * mb * bv * (1.f - bv);
+  }
+  a_d_b_d = av * ma;
+  return dsv * wc * ma * (1.f - av * av);
+}
+
 struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   GateBwdCtx g;
   const float *Wa, *Wb;    // [D x H]
@@ -135,6 +155,7 @@ int gate_parts(int D, int gated, int64_t N);
 int launch_gate_fwd(GateFwdParams p, hipStream_t st);
 int pool_groups(int64_t N);
 int launch_pool(PoolParams p, hipStream_t st);
+int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
 int bwd_dh_fused_groups(int64_t N, int H);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials

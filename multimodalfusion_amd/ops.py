@@ -41,7 +41,9 @@ class AmilPoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed):
-        x = _f32c(x)
+        # a bf16 bag selects the bf16-storage kernels (include/mmf_amil.h: mmf_amil_bf16_*); parameters stay fp32
+        bf16 = x.dtype == torch.bfloat16
+        x = x.contiguous() if bf16 else _f32c(x)
         W1, b1, Wa, ba, Wc, bc = map(_f32c, (W1, b1, Wa, ba, Wc, bc))
         Wb, bb = _f32c(Wb), _f32c(bb)
         if x.dim() != 2:
@@ -55,12 +57,15 @@ class AmilPoolFn(torch.autograd.Function):
                      Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
                      Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF)
         l = lib()
-        nbytes = l.mmf_amil_workspace_bytes(N, L, H, D, d.gated)
+        ws_fn, fwd_fn = ((l.mmf_amil_bf16_workspace_bytes, l.mmf_amil_bf16_forward) if bf16
+                         else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
+        nbytes = ws_fn(N, L, H, D, d.gated)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         M = torch.empty((1, H), dtype=torch.float32, device=x.device)
         A_raw = torch.empty((1, N), dtype=torch.float32, device=x.device)
-        check(l.mmf_amil_forward(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), stream_ptr()),
-              "mmf_amil_forward")
+        check(fwd_fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), stream_ptr()),
+              "mmf_amil_bf16_forward" if bf16 else "mmf_amil_forward")
+        ctx.bf16 = bf16
         ctx.desc_args = (N, L, H, D, bool(gated), float(p_h), float(p_att), int(seed) & 0xFFFFFFFF)
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw)
@@ -80,12 +85,15 @@ class AmilPoolFn(torch.autograd.Function):
         new = lambda ref: torch.empty_like(ref)
         dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
         dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
+        if ctx.bf16 and ctx.needs_input_grad[0]:
+            raise _lib.MmfError("a bf16 bag is a leaf: no input gradient on the bf16 path")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         g = AmilGrads(dW1=ptr(dW1), db1=ptr(db1), dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb), dbb=ptr(dbb),
                       dWc=ptr(dWc), dbc=ptr(dbc), dx=ptr(dx))
         ws = ctx.ws
-        check(lib().mmf_amil_backward(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(M), ptr(A_raw),
-                                      ptr(gM), ptr(gA), C.byref(g), stream_ptr()), "mmf_amil_backward")
+        bwd_fn = lib().mmf_amil_bf16_backward if ctx.bf16 else lib().mmf_amil_backward
+        check(bwd_fn(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(M), ptr(A_raw),
+                     ptr(gM), ptr(gA), C.byref(g), stream_ptr()), "mmf_amil_bf16_backward" if ctx.bf16 else "mmf_amil_backward")
         return dx, dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, None, None, None, None
 
 
@@ -263,6 +271,8 @@ class DenseFn(torch.autograd.Function):
         B, K = x.shape
         N = W.shape[0]
         dpre = torch.empty_like(y)
+        if ctx.bf16 and ctx.needs_input_grad[0]:
+            raise _lib.MmfError("a bf16 bag is a leaf: no input gradient on the bf16 path")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W)
         db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None

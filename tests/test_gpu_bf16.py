@@ -1,0 +1,136 @@
+"""GPU parity of the bf16-storage path (mmf_amil_bf16_*; BASELINE config 5) through the drop-in head.
+
+Two references:
+  * oracle/bf16_port.py with the kernels' rounding points (pinned on CPU by tests/test_oracle_bf16.py).  HIP and oracle
+    then differ only by fp32-vs-fp64 accumulation, which can flip a bf16 rounding of a saved activation in a few
+    elements (1 bf16 ulp = 2^-8 relative); tolerances: scores/hazards 2e-3 abs, loss 1e-3, gradients 1 % in norm;
+  * the fp32/fp64 reference fixtures: bf16 quantisation only (scores 3e-2, hazards 1e-2, gradients 15 % in norm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bf16_port, cases
+from oracle import inputs as gen
+from test_gpu_path import DEV, _grads, _load
+
+pytestmark = pytest.mark.gpu
+
+ZERO_GRADS = ("attention_c.bias", "module.2.bias", "module.3.bias")     # analytically zero
+
+
+def run_path_hip_bf16(m, monkeypatch, x_np):
+    from multimodalfusion_amd import ops
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    sd, _, _ = cases.path_inputs(m)
+    model = _load(MIL_Attention_fc_surv_path(gate_path=m["gated"], model_size_wsi=m["size"],
+                                             dropout=m["dropout"], n_classes=m["K"]), sd)
+    if m["train"]:
+        model.train()
+        monkeypatch.setattr(ops, "next_dropout_seed", lambda: m["mask_seed"])
+    else:
+        model.eval()
+    xt = torch.as_tensor(x_np).to(torch.float32).to(torch.bfloat16).to(DEV)
+    hz, S, Yh, A_raw = model(path_features=xt)
+    loss = NLLSurvLoss(alpha=m["alpha"])(hazards=hz, S=S, Y=torch.tensor([m["y"]], device=DEV),
+                                         c=torch.tensor([float(m["c"])], device=DEV))
+    loss.backward()
+    with torch.no_grad():
+        M = None if m["train"] else model(path_features=xt, return_features=True).cpu().numpy()
+    torch.cuda.synchronize()
+    return dict(hazards=hz.detach().cpu().numpy(), S=S.detach().cpu().numpy(), Y_hat=Yh.cpu().numpy(),
+                A_raw=A_raw.detach().cpu().numpy(), loss=float(loss), M=M, grads=_grads(model))
+
+
+def compare_bf16(res, ref, tag, a_tol, h_tol, l_tol, g_rel):
+    assert abs(res["loss"] - float(ref["loss"])) <= l_tol, (tag, res["loss"], float(ref["loss"]))
+    np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=h_tol, err_msg=tag)
+    np.testing.assert_allclose(res["A_raw"], ref["A_raw"], rtol=0, atol=a_tol, err_msg=tag)
+    if res.get("M") is not None:
+        np.testing.assert_allclose(res["M"], ref["M"], rtol=0, atol=a_tol, err_msg=tag)
+    for k, g in ref["grads"].items():
+        if k.endswith(ZERO_GRADS):
+            assert float(np.abs(res["grads"][k]).max()) <= 1e-4, (tag, k)
+            continue
+        err, nrm = float(np.linalg.norm(res["grads"][k] - g)), float(np.linalg.norm(g))
+        assert err <= g_rel * nrm + 1e-6, f"{tag} grad {k}: |err| {err:.3e} vs |g| {nrm:.3e}"
+
+
+def _oracle(m, x_q):
+    sd, _, masks = cases.path_inputs(m)
+    return bf16_port.path_step_bf16(sd, x_q, m["y"], m["c"], m["alpha"], gated=m["gated"], dropout=m["dropout"],
+                                    masks=masks)
+
+
+def _xq(m):
+    _, x, _ = cases.path_inputs(m)
+    return bf16_port.rb(bf16_port._t(x)).numpy()
+
+
+def test_bf16_path_golden_cases(golden, monkeypatch):
+    """Every small path fixture (gated/ungated, small/big, eval/train masks, ragged N) in bf16 storage."""
+    g = golden("path")
+    n = 0
+    for name, m in g.meta.items():
+        if m["N"] > 2000:
+            continue
+        xq = _xq(m)
+        res = run_path_hip_bf16(m, monkeypatch, xq)
+        compare_bf16(res, _oracle(m, xq), name + "/bf16-oracle", a_tol=2e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
+        compare_bf16(res, cases.run_path(m), name + "/fp64-reference", a_tol=3e-2, h_tol=1e-2, l_tol=3e-2, g_rel=0.15)
+        n += 1
+    assert n >= 8
+
+
+@pytest.mark.parametrize("N", [4099, 20000])
+def test_bf16_path_mid_sizes(monkeypatch, N):
+    """Sizes that use several row tiles and several K splits (ragged last tile and last split)."""
+    m = dict(seed=3, gated=True, size="small", K=4, dropout=True, bias_std=0.02, x_seed=77, N=N, train=True,
+             mask_seed=4242, y=1, c=0, alpha=0.0)
+    xq = _xq(m)
+    res = run_path_hip_bf16(m, monkeypatch, xq)
+    compare_bf16(res, _oracle(m, xq), f"N={N}", a_tol=2e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
+
+
+def test_bf16_100k_properties():
+    """BASELINE config-5 size (100k x 1024, bf16): size-independent properties of the path."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    torch.manual_seed(5)
+    N = 100_000
+    model = MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=False, n_classes=4).to(DEV).eval()
+    x = torch.randn(N, 1024, device=DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        A = model(path_features=x, attention_only=True)
+        M = model(path_features=x, return_features=True)
+        perm = torch.randperm(N, device=DEV)
+        A_p = model(path_features=x[perm].contiguous(), attention_only=True)
+        M_p = model(path_features=x[perm].contiguous(), return_features=True)
+        # instance scores do not depend on the other instances: bit-identical under a permutation of the bag
+        assert torch.equal(A_p[0], A[0][perm])
+        # the pooled embedding is permutation invariant up to fp32 summation order
+        assert float((M_p - M).abs().max()) <= 1e-4
+        # duplicating the bag leaves softmax pooling unchanged
+        M2 = model(path_features=torch.cat([x[:50_000], x[:50_000]]).contiguous(), return_features=True)
+        M1 = model(path_features=x[:50_000].contiguous(), return_features=True)
+        assert float((M2 - M1).abs().max()) <= 1e-4
+    # gradients: finite, and db1 equals the column sums of du implied by dW1 on a constant-1 probe column
+    model.train()
+    hz, S, Yh, A_raw = model(path_features=x)
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.0], device=DEV))
+    loss.backward()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    assert torch.isfinite(loss)
+
+
+def test_bf16_constant_column_gives_bias_gradient(monkeypatch):
+    """dW1[:, j] for a feature column that is identically 1 must equal db1 (both are column sums of du)."""
+    m = dict(seed=9, gated=True, size="small", K=4, dropout=False, bias_std=0.02, x_seed=5, N=3000, train=False,
+             mask_seed=0, y=2, c=0, alpha=0.0)
+    xq = _xq(m)
+    xq[:, 17] = 1.0
+    res = run_path_hip_bf16(m, monkeypatch, xq)
+    dW1, db1 = res["grads"]["attention_net_WSI.0.weight"], res["grads"]["attention_net_WSI.0.bias"]
+    np.testing.assert_allclose(dW1[:, 17], db1, rtol=1e-4, atol=1e-7)
