@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
     ap.add_argument("--graph", action="store_true", help="also time N = 1k / 10k as captured hipGraph steps (extra key)")
     ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (extra key, never `value`)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the bag and saved activations; f32 is the BASELINE metric, bf16 is config 5 "
+                         "(bf16 MFMA, fp32 accumulate/epilogues; HBM roofline)")
     return ap.parse_args()
 
 
@@ -50,8 +53,9 @@ def flops_per_bag(N, L=1024, H=256, D=256):
     return (fwd + bwd) * N
 
 
-def bytes_per_bag(N, L=1024):
-    return 2 * 4 * L * N + 4 * N + 4.7e6
+def bytes_per_bag(N, bf16=False, L=1024):
+    """Algorithmic bytes: x read once forward and once for dW1, A_raw, weights + grads."""
+    return 2 * (2 if bf16 else 4) * L * N + 4 * N + 4.7e6
 
 
 def build_model(dev, eval_mode):
@@ -290,6 +294,9 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     x = torch.randn(N, 1024, device=dev, generator=g)      # synthetic bag, resident in HBM
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        x = x.to(torch.bfloat16)
     step = make_step(model, x, dev, flat, world)
 
     dt = time_steps(step, args.steps, args.warmup, world)
@@ -300,8 +307,8 @@ def main():
         "metric": "bags/sec fwd+bwd, path-AMIL 50k x 1024 synthetic bag" if N == 50000 else f"bags/sec fwd+bwd, path-AMIL {N} x 1024 synthetic bag",
         "value": value, "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) bag per GPU per step, "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) {'bf16 ' if bf16 else ''}bag per GPU per step, "
                                f"nll_surv alpha=0, {'eval' if args.eval_mode else 'train (1 dropout mask)'} mode, "
                                f"fwd+loss+bwd, grads materialised" + (", 1 RCCL all-reduce/step" if world > 1 else ""),
                    "instances_per_bag": N, "parallelism": f"dp{world} (one bag per GPU)"},
@@ -319,7 +326,21 @@ def main():
             "bwd_dh_kernel": 2 * 2 * 256 * 256 * N,
             "tn_kernel": (2 * 256 * 1024 + 2 * 2 * 256 * 256) * N,
         }
-        if dom in kflops:
+        # bf16 storage: every kernel is HBM-bound; minimal bytes each kernel must move per launch
+        kbytes = {
+            "linear_bf16_kernel": N * (1024 * 2 + 256 * 2),                    # x read, h written
+            "gate_bf16_kernel": N * (256 * 2 + 2 * 256 * 2 + 2 * 4),           # h read; a, b, 2 score parts written
+            "pool_partial_bf16_kernel": N * (256 * 2 + 3 * 4),                 # h read; score parts read, A_raw written
+            "dh_bf16_kernel": N * (2 * 256 * 2 + 256 * 2 + 256 * 2),           # a, b, h read; du written
+            "tn_bf16_kernel": N * (256 * 2 + 1024 * 2 + 2 * 256 * 2 + 256 * 2),  # du, x, a, b, h read
+        }
+        if bf16 and dom in kbytes:
+            t_us = prof[dom]["avg_us"]
+            ach = kbytes[dom] / (t_us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_us,
+                               "bytes_per_launch": kbytes[dom]}
+        elif dom in kflops:
             t_us = prof[dom]["avg_us"]
             ach = kflops[dom] / (t_us * 1e-6) / 1e12
             traffic = None     # HBM bytes per launch from the committed PMC passes (same workload only)
@@ -335,8 +356,8 @@ def main():
         tot = flops_per_bag(N)
         out["whole_step"] = {"tflops": tot / (ms_per_step * 1e-3) / 1e12,
                              "frac_fp32_mfma_peak": tot / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                             "algorithmic_gbs": bytes_per_bag(N) / (ms_per_step * 1e-3) / 1e9,
-                             "frac_hbm_peak": bytes_per_bag(N) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "algorithmic_gbs": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9,
+                             "frac_hbm_peak": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}
         if args.extra_sizes and world == 1:
             extra = {}
@@ -350,7 +371,7 @@ def main():
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
         if args.h2d and world == 1:
             out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

@@ -18,6 +18,30 @@
 
 namespace mmf {
 
+// Diagnostic build only (-DMMF_STAMPS): per-kernel phase cycles, kernel k in slots [8k, 8k+8):
+// {prologue, main loop, epilogue, -, -, -, -, waves}.  The shipped library contains none of this.
+#ifdef MMF_STAMPS
+static __device__ unsigned long long g_bst[32];
+#define BST_BEGIN() unsigned long long bst_prev = stamp_now(), bst_t
+#define BST_MARK(k, slot) do { bst_t = stamp_now(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_bst[8 * (k) + (slot)], bst_t - bst_prev); bst_prev = bst_t; } while (0)
+#define BST_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_bst[8 * (k) + 7], 1ull); } while (0)
+#else
+#define BST_BEGIN()
+#define BST_MARK(k, slot)
+#define BST_COUNT(k)
+#endif
+enum { BST_LIN = 0, BST_GATE = 1, BST_DH = 2, BST_TN = 3 };
+
+void debug_stamps_bf16(unsigned long long* out32) {
+#ifdef MMF_STAMPS
+  hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bst), 32 * sizeof(unsigned long long));
+  unsigned long long z[32] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_bst), z, sizeof z);
+#else
+  for (int i = 0; i < 32; ++i) out32[i] = 0;
+#endif
+}
+
 template <class T, class P>
 static int launch_tiled_b(const char* name, void (*kern)(P), const P& p, int grid, int lds_bytes, hipStream_t st) {
   if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return e;
@@ -39,7 +63,8 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   if (e >= s.rows * s.cols) return;
   const int r = e / s.cols, c = e - r * s.cols;
   const bf16_t v = f2bf(s.src[e]);
-  if (s.transpose) s.dst[(size_t)c * s.dst_ld + s.c0 + r] = v;
+  if (s.transpose == 2) s.dst[(size_t)c * s.dst_ld + s.c0 + (r >> 5) * 64 + (r & 31)] = v;   // 32-row blocks, 64 apart
+  else if (s.transpose) s.dst[(size_t)c * s.dst_ld + s.c0 + r] = v;
   else s.dst[(size_t)r * s.dst_ld + s.c0 + c] = v;
 }
 
@@ -76,12 +101,15 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
+  BST_BEGIN();
   LoadK<T::BM, T::NT> la;
   la.init(reinterpret_cast<const float*>(p.x), p.K / 2, row0, (int)p.M);
   LoadK<T::BN, T::NT> lb;
   lb.init(reinterpret_cast<const float*>(p.w), p.K / 2, col0, p.N);
   f32x16 acc[T::MB][T::NB];
+  BST_MARK(BST_LIN, 0);
   gemm_mainloop<T>(la, lb, p.K / 64, lds, acc);
+  BST_MARK(BST_LIN, 1);
 
   const uint32_t thr = drop_threshold(p.drop_p);
   const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -110,6 +138,8 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
       *reinterpret_cast<uint2*>(p.y + (size_t)row * p.N + col) = pack4(y[0], y[1], y[2], y[3]);
     }
   });
+  BST_MARK(BST_LIN, 2);
+  BST_COUNT(BST_LIN);
 }
 
 int launch_linear_bf16(LinearBfParams p, hipStream_t st) {
@@ -172,12 +202,15 @@ __global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, d0 = nt * DT;
+  BST_BEGIN();
   LoadK<T::BM, T::NT> la;
   la.init(reinterpret_cast<const float*>(p.h), p.H / 2, row0, (int)p.N);
   LoadGateWB<T::BN, T::NT, GATED> lb;
   lb.init(p.Wa, p.Wb, p.H, p.D, d0);
   f32x16 acc[T::MB][T::NB];
+  BST_MARK(BST_GATE, 0);
   gemm_mainloop<T>(la, lb, p.H / 64, lds, acc);
+  BST_MARK(BST_GATE, 1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
@@ -255,6 +288,8 @@ __global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
       p.s_part[(size_t)nt * p.N + row] = s;
     }
   }
+  BST_MARK(BST_GATE, 2);
+  BST_COUNT(BST_GATE);
 }
 
 int gate_parts_bf16(int D, int gated) { return gated ? (D + 127) / 128 : (D + 255) / 256; }
@@ -348,8 +383,13 @@ int launch_pool_bf16(PoolBfParams pb, hipStream_t st) {
 }
 
 // =============================================================================================
-// K-dh : du = bf16((dP.Wab + p dM) . relu'(h) . scale_h),  dP built on the fly, K-prep fused
+// K-dh : du = bf16((dP.Wab + p dM) . relu'(h) . scale_h).  K-prep is fused in front; the loader builds dP from
+//        a, b, ds, writes it to LDS (A operand) AND to HBM (the TN kernel's operand for dWa/dWb/dba/dbb), and
+//        takes the dWc column sums on the way.
 // =============================================================================================
+// k order of a gated chunk (64 k): [0, 32) = d pre-tanh of attention dims 32 kt .. 32 kt + 31, [32, 64) = d
+// pre-sigmoid of the SAME dims, so a thread loads the 8 a and 8 b of its (instance, dims) once and emits both;
+// WabT is stored in the same interleaved order (launch side: CvtSeg::transpose == 2).  Ungated: 64 plain dims.
 __device__ inline GateBwdCtx gate_ctx(const GateBwdBf& g) {
   GateBwdCtx c{};
   c.D = g.D; c.gated = g.gated; c.drop_p = g.drop_p;
@@ -358,123 +398,207 @@ __device__ inline GateBwdCtx gate_ctx(const GateBwdBf& g) {
   return c;
 }
 
-template <int ROWS, int NT>
-struct LoadPB {    // A[i][k] = dP (k = [d pre-tanh | d pre-sigmoid]), k-contiguous image, 64 k per chunk
-  using Map = KMap<ROWS, NT>;
+template <int ROWS, int NT, bool GATED>
+struct LoadPB {
+  static constexpr int PPR = GATED ? 4 : 8;                 // 8-dim pieces per row and chunk
+  static constexpr int DPC = GATED ? 32 : 64;               // attention dims per chunk
+  static constexpr int NV = ROWS * PPR / NT;
+  static_assert((ROWS * PPR) % NT == 0 && NT % PPR == 0, "slot ownership must be exact");
   GateBwdCtx gc;
   rsrc_t ra, rb, rwc;
-  int row0, tid, part, d0, D;
+  int row0, nrows, tid, d0, D, mstk;
+  bool write_dp;
   uint32_t thr;
   float dscale;
-  unsigned voff[Map::NV];
-  float dsr[Map::NV];
-  float4 ra4[Map::NV], rb4[Map::NV], wc_lo, wc_hi;
-  __device__ inline void init_lds(const GateBwdBf& g, int row0_, int nrows, const float* ds_lds) {
-    gc = gate_ctx(g); D = g.D; row0 = row0_; tid = threadIdx.x;
+  bf16_t* dP;          // [N x mstk]
+  float* dwc_l;        // LDS [waves][D]
+  unsigned voff[NV];
+  float dsr[NV];
+  float4 ra4[NV], rb4[NV], wc_lo, wc_hi;
+  __device__ static inline int row(int tid, int i) { return (tid + i * NT) / PPR; }
+  __device__ static inline int piece(int tid) { return tid % PPR; }
+  __device__ inline void init_lds(const GateBwdBf& g, int row0_, int nrows_, const float* ds_lds, bf16_t* dP_, bool write_dp_,
+                                  float* dwc_l_) {
+    gc = gate_ctx(g); gc.gated = GATED ? 1 : 0;
+    D = g.D; mstk = GATED ? 2 * D : D; row0 = row0_; nrows = nrows_; tid = threadIdx.x;
+    dP = dP_; write_dp = write_dp_; dwc_l = dwc_l_;
     thr = drop_threshold(g.drop_p);
     dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
     const unsigned bytes = (unsigned)nrows * (unsigned)D * 2u;
     ra = make_rsrc(g.a, bytes);
-    rb = make_rsrc(g.gated ? g.b : g.a, bytes);
+    rb = make_rsrc(GATED ? g.b : g.a, bytes);
     rwc = make_rsrc(g.Wc, (unsigned)D * 4u);
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      const int rl = Map::row(tid, i), rr = row0 + rl;
-      const bool ok = Map::valid(tid, i) && rr < nrows;
-      voff[i] = ok ? ((unsigned)rr * (unsigned)D + 8u * Map::c4(tid, i)) * 2u : OOB;
+    for (int i = 0; i < NV; ++i) {
+      const int rl = row(tid, i), rr = row0 + rl;
+      const bool ok = rr < nrows;
+      voff[i] = ok ? ((unsigned)rr * (unsigned)D + 8u * piece(tid)) * 2u : OOB;
       dsr[i] = ok ? ds_lds[rl] : 0.f;
     }
   }
   __device__ inline void load(int kt) {
-    const int nka = D / 64;
-    part = kt >= nka ? 1 : 0;
-    d0 = (kt - part * nka) * 64;
-    wc_lo = bld4(rwc, 32u * (tid & 7), (unsigned)d0 * 4u);
-    wc_hi = bld4(rwc, 32u * (tid & 7) + 16u, (unsigned)d0 * 4u);
+    d0 = kt * DPC;
+    wc_lo = bld4(rwc, 32u * piece(tid), (unsigned)d0 * 4u);
+    wc_hi = bld4(rwc, 32u * piece(tid) + 16u, (unsigned)d0 * 4u);
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       ra4[i] = bld4(ra, voff[i], (unsigned)d0 * 2u);
-      rb4[i] = bld4(rb, voff[i], (unsigned)d0 * 2u);
+      if (GATED) rb4[i] = bld4(rb, voff[i], (unsigned)d0 * 2u);
     }
   }
-  __device__ inline void store(float* lds) const {
-    const int c = d0 + 8 * (tid & 7);
+  __device__ inline void store(float* lds) {
+    const int c = d0 + 8 * piece(tid);
     const float wc[8] = {wc_lo.x, wc_lo.y, wc_lo.z, wc_lo.w, wc_hi.x, wc_hi.y, wc_hi.z, wc_hi.w};
+    float wsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      if (!Map::valid(tid, i)) continue;
-      const int rr = row0 + Map::row(tid, i);
+    for (int i = 0; i < NV; ++i) {
+      const int rl = row(tid, i), rr = row0 + rl;
       const uint32_t idx = (uint32_t)rr * (uint32_t)D + (uint32_t)c;
-      float av[8], bv[8], o[8], dummy;
-      unpack8(ra4[i], av);
-      unpack8(rb4[i], bv);
+      const float dsv = dsr[i];
+      // one packed dword (2 dims) at a time: keeps the live set small (the 256-row tile is at the register limit)
+      const uint32_t aw[4] = {__float_as_uint(ra4[i].x), __float_as_uint(ra4[i].y), __float_as_uint(ra4[i].z), __float_as_uint(ra4[i].w)};
+      const uint32_t bw[4] = {__float_as_uint(rb4[i].x), __float_as_uint(rb4[i].y), __float_as_uint(rb4[i].z), __float_as_uint(rb4[i].w)};
+      uint32_t pw[4], qw[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = gate_dp(gc, part, av[e], bv[e], wc[e], dsr[i], idx + e, thr, dscale, dummy);
-      st4(lds + Map::lds(tid, i), pack8(o));
+      for (int q = 0; q < 4; ++q) {
+        float a0, a1, b0 = 0.f, b1 = 0.f, w0, w1;
+        unpack2(aw[q], a0, a1);
+        if (GATED) unpack2(bw[q], b0, b1);
+        const float oa0 = gate_dp(gc, 0, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
+        const float oa1 = gate_dp(gc, 0, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
+        pw[q] = pack2(oa0, oa1);
+        if (GATED) {
+          const float ob0 = gate_dp(gc, 1, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
+          const float ob1 = gate_dp(gc, 1, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
+          qw[q] = pack2(ob0, ob1);
+        }
+        wsum[2 * q] += dsv * w0;
+        wsum[2 * q + 1] += dsv * w1;
+      }
+      const float4 pa = make_float4(__uint_as_float(pw[0]), __uint_as_float(pw[1]), __uint_as_float(pw[2]), __uint_as_float(pw[3]));
+      float* dst = lds + rl * KSTR + 4 * piece(tid);
+      st4(dst, pa);
+      float4 pb4 = zero4();
+      if (GATED) {
+        pb4 = make_float4(__uint_as_float(qw[0]), __uint_as_float(qw[1]), __uint_as_float(qw[2]), __uint_as_float(qw[3]));
+        st4(dst + 16, pb4);
+      }
+      if (write_dp && rr < nrows) {
+        bf16_t* o = dP + (size_t)rr * mstk + c;
+        *reinterpret_cast<float4*>(o) = pa;
+        if (GATED) *reinterpret_cast<float4*>(o + D) = pb4;
+      }
+    }
+    // dWc partial of this chunk's dims: sum over the wave's rows (lanes that share `piece`), one LDS row per wave
+    constexpr int FIRST = PPR;          // lane bits above the piece bits select the row
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = wsum[e];
+#pragma unroll
+      for (int o = FIRST; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      wsum[e] = v;
+    }
+    if ((tid & 63) < PPR && c < D) {
+      float* o = dwc_l + (tid >> 6) * D + c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = wsum[e];
     }
   }
 };
 
-template <class T>
+template <class T, bool GATED>
 __global__ __launch_bounds__(T::NT) void dh_bf16_kernel(DhBfParams p) {
   extern __shared__ __align__(16) float lds[];
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers
+  constexpr int NW = T::NT / 64;
+  float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, [BM] g, [16] scratch, [NW][D] dWc -- behind the staging buffers
   float* p_l = ds_l + T::BM;
+  float* g_l = p_l + T::BM;
+  float* red = g_l + T::BM;
+  float* dwc_l = red + 16;
+  BST_BEGIN();
   {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
-    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
-    float dmm = 0.f;
-    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
-    dmm = wave_sum(dmm);
-    float dm_l[2][8];                              // dM of this lane's columns 8 lane + 512 q (H <= 1024)
+    // g_i = dM.h_i: every wave takes BM/NW rows; lanes cover 16-byte pieces of h, 8 independent loads in flight
+    const int LPR = p.H / 8;                       // 16-byte pieces per row: 32, 64 or 128
+    constexpr int RPW = T::BM / NW;                // rows per wave
+    const int cl = LPR >= 64 ? lane : (lane & (LPR - 1));
+    float dm_l[2][8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int c = 8 * lane + 512 * q;
+      const int c = 8 * (cl + 64 * q);
       const float4 lo = c < p.H ? ld4(p.dM + c) : zero4(), hi = c < p.H ? ld4(p.dM + c + 4) : zero4();
       dm_l[q][0] = lo.x; dm_l[q][1] = lo.y; dm_l[q][2] = lo.z; dm_l[q][3] = lo.w;
       dm_l[q][4] = hi.x; dm_l[q][5] = hi.y; dm_l[q][6] = hi.z; dm_l[q][7] = hi.w;
     }
-    float dbc = 0.f;
-    constexpr int NW = T::NT / 64;
-    for (int r0 = wave * 4; r0 < T::BM; r0 += NW * 4) {
-      float g[4];
+    const int total_j = RPW * LPR / 64;            // wave-wide loads for this wave's rows
+    for (int jb = 0; jb < total_j; jb += 8) {
+      float4 raw[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = row0 + r0 + u;
+      for (int u = 0; u < 8; ++u) {
+        const int pidx = lane + 64 * (jb + u);
+        const int row = row0 + wave * RPW + pidx / LPR;
         const int rc = row < p.N ? row : (int)p.N - 1;
+        raw[u] = ld4(reinterpret_cast<const float*>(p.h + (size_t)rc * p.H + 8 * (pidx % LPR)));
+      }
+      float part[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float hv[8];
+        unpack8(raw[u], hv);
+        const int q = LPR > 64 ? ((jb + u) & 1) : 0;
         float acc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          if (8 * lane + 512 * q < p.H) {
-            float hv[8];
-            unpack8(ld4(reinterpret_cast<const float*>(p.h + (size_t)rc * p.H + 8 * lane + 512 * q)), hv);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += hv[k] * dm_l[q][k];
-          }
-        g[u] = acc;
+        for (int k = 0; k < 8; ++k) acc += hv[k] * (q ? dm_l[1][k] : dm_l[0][k]);
+        part[u] = acc;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) g[u] = wave_sum(g[u]);
-      if (lane < 4 && r0 + lane < T::BM) {
-        const int row = row0 + r0 + lane;
-        const float gv = lane == 0 ? g[0] : (lane == 1 ? g[1] : (lane == 2 ? g[2] : g[3]));
-        float pi = 0.f, d = 0.f;
-        if (row < p.N) {
-          pi = __expf(p.A_raw[row] - smax) * inv;
-          d = pi * (gv - dmm) + (p.gA ? p.gA[row] : 0.f);
-          if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+      for (int u = 0; u < 8; ++u) {
+        float v = part[u];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+        if (LPR >= 64) v += __shfl_xor(v, 32, 64);
+        part[u] = v;
+      }
+      if (LPR == 32) {
+        if ((lane & 31) == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g_l[wave * RPW + 2 * (jb + u) + (lane >> 5)] = part[u];
         }
-        ds_l[r0 + lane] = d;
-        p_l[r0 + lane] = pi;
-        dbc += d;
+      } else if (LPR == 64) {
+        if (lane == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g_l[wave * RPW + jb + u] = part[u];
+        }
+      } else {
+        if (lane == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) g_l[wave * RPW + (jb + u) / 2] = part[u] + part[u + 1];
+        }
       }
     }
+    float dmm = 0.f;
+    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
+    dmm = wave_sum(dmm);
+    __syncthreads();
+    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
+    float dbc = 0.f;
+    for (int r = tid; r < T::BM; r += T::NT) {
+      const int row = row0 + r;
+      float pi = 0.f, d = 0.f;
+      if (row < p.N) {
+        pi = __expf(p.A_raw[row] - smax) * inv;
+        d = pi * (g_l[r] - dmm) + (p.gA ? p.gA[row] : 0.f);
+        if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+      }
+      ds_l[r] = d;
+      p_l[r] = pi;
+      dbc += d;
+    }
     dbc = wave_sum(dbc);
-    float* red = p_l + T::BM;
     if (lane == 0) red[wave] = dbc;
     __syncthreads();
     if (tid == 0 && nt == 0) {
@@ -483,13 +607,23 @@ __global__ __launch_bounds__(T::NT) void dh_bf16_kernel(DhBfParams p) {
       p.dbc_part[mt] = s;
     }
   }
-  const int mstk = p.g.gated ? 2 * p.g.D : p.g.D;
-  LoadPB<T::BM, T::NT> la;
-  la.init_lds(p.g, row0, (int)p.N, ds_l);
+  const int mstk = GATED ? 2 * p.g.D : p.g.D;
+  LoadPB<T::BM, T::NT, GATED> la;
+  la.init_lds(p.g, row0, (int)p.N, ds_l, p.dP, nt == 0, dwc_l);
   LoadK<T::BN, T::NT> lb;
   lb.init(reinterpret_cast<const float*>(p.WabT), mstk / 2, col0, p.H);
   f32x16 acc[T::MB][T::NB];
+  BST_MARK(BST_DH, 0);
   gemm_mainloop<T>(la, lb, mstk / 64, lds, acc);
+  BST_MARK(BST_DH, 1);
+  if (nt == 0) {                               // per-tile dWc partial: sum the waves' rows (the loop's last barrier has passed)
+    for (int d = tid; d < p.g.D; d += T::NT) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += dwc_l[w * p.g.D + d];
+      p.dwc_part[(size_t)mt * p.g.D + d] = s;
+    }
+  }
   float4 dm4[T::NB];
 #pragma unroll
   for (int nb = 0; nb < T::NB; ++nb) {
@@ -523,23 +657,30 @@ __global__ __launch_bounds__(T::NT) void dh_bf16_kernel(DhBfParams p) {
       *reinterpret_cast<uint2*>(p.du + (size_t)row * p.H + col) = pack4(d0, d1, d2, d3);
     }
   });
+  BST_MARK(BST_DH, 2);
+  BST_COUNT(BST_DH);
 }
 
 int dh_bf16_row_tiles(int64_t N) { return (int)((N + 127) / 128); }   // upper bound of mt_count (128-row tiles)
-int dh_bf16_tiles_used(int64_t N, int ntn) { const int bm = pick_bm(N, ntn); return (int)((N + bm - 1) / bm); }
+int dh_bf16_tiles_used(int64_t N, int ntn) { (void)ntn; return (int)((N + 127) / 128); }
 
 template <class T>
 static int launch_dh_bf16_t(DhBfParams p, hipStream_t st) {
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM);
-  const int bytes = T::LDS_BYTES + (2 * T::BM + 16) * 4;
-  return launch_tiled_b<T>("dh_bf16_kernel", dh_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), bytes, st);
+  const int bytes = T::LDS_BYTES + (3 * T::BM + 16 + (T::NT / 64) * p.g.D) * 4;
+  if (bytes > 160 * 1024) return MMF_ERR_SHAPE;
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  return p.g.gated ? launch_tiled_b<T>("dh_bf16_kernel", dh_bf16_kernel<T, true>, p, grid, bytes, st)
+                   : launch_tiled_b<T>("dh_bf16_kernel", dh_bf16_kernel<T, false>, p, grid, bytes, st);
 }
 
 int launch_dh_bf16(DhBfParams p, hipStream_t st) {
   if (p.g.D % 64 != 0 || p.H % 256 != 0 || p.H > 1024) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
   p.nt_count = p.H / 256;
-  return pick_bm(p.N, p.nt_count) == 128 ? launch_dh_bf16_t<TileB128>(p, st) : launch_dh_bf16_t<TileB256>(p, st);
+  // 128-row tiles only: with the on-the-fly dP loader the 256-row tile needs > 256 VGPRs and spills inside the loop,
+  // where a scratch reload waits on vmcnt behind the prefetch and exposes the whole HBM latency (measured: 219 vs 162 us)
+  return launch_dh_bf16_t<TileB128>(p, st);
 }
 
 // =============================================================================================
@@ -609,89 +750,6 @@ struct LoadTPlain {
   }
 };
 
-// A[k = instance][m] = dP of DT attention dims d0 .. d0+DT-1: gated, image columns [0, DT) = d pre-tanh and
-// [DT, 2 DT) = d pre-sigmoid of the same dims (a, b, ds loaded once for both); ungated, DT = ROWS.
-template <int ROWS, int NT, int PITCH, bool GATED>
-struct LoadTGate {
-  static constexpr int DT = GATED ? ROWS / 2 : ROWS;
-  using Map = TMap<DT, NT>;
-  GateBwdCtx gc;
-  rsrc_t ra, rb, rds;
-  int d0, kbase, tid, kt_loaded, D;
-  bool do_sum;
-  uint32_t thr;
-  float dscale;
-  unsigned db;
-  unsigned voff[Map::NV], voff_ds[Map::NV];
-  float4 ra4[Map::NV], rb4[Map::NV];
-  float wc[8], dsr[Map::NV];
-  float cs_a[8], cs_b[8], cs2[8];
-  __device__ inline void init(const GateBwdBf& g, int d0_, int kbase_, int kmax, bool do_sum_) {
-    gc = gate_ctx(g); gc.gated = GATED ? 1 : 0;
-    D = g.D; d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
-    thr = drop_threshold(g.drop_p);
-    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { cs_a[e] = 0.f; cs_b[e] = 0.f; cs2[e] = 0.f; }
-    db = (unsigned)D * 2u;
-    const unsigned rows = (unsigned)(kmax > 0 ? kmax : 0);
-    ra = make_rsrc(g.a, rows * db);
-    rb = make_rsrc(GATED ? g.b : g.a, rows * db);
-    rds = make_rsrc(g.ds, rows * 4u);
-    const int c = d0 + 8 * Map::piece(tid);
-    const bool ok = c < D;
-    const rsrc_t rwc = make_rsrc(g.Wc, (unsigned)D * 4u);
-    const float4 lo = bld4(rwc, ok ? (unsigned)c * 4u : OOB, 0), hi = bld4(rwc, ok ? (unsigned)c * 4u + 16u : OOB, 0);
-    wc[0] = lo.x; wc[1] = lo.y; wc[2] = lo.z; wc[3] = lo.w; wc[4] = hi.x; wc[5] = hi.y; wc[6] = hi.z; wc[7] = hi.w;
-#pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      voff[i] = ok ? (unsigned)Map::krow(tid, i) * db + (unsigned)c * 2u : OOB;
-      voff_ds[i] = ok ? (unsigned)Map::krow(tid, i) * 4u : OOB;
-    }
-    kt_loaded = 0;
-  }
-  __device__ inline void load(int kt) {
-    kt_loaded = kt;
-    const unsigned k0 = (unsigned)(kbase + kt * TNB_KCH);
-#pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      ra4[i] = bld4(ra, voff[i], k0 * db);
-      if (GATED) rb4[i] = bld4(rb, voff[i], k0 * db);
-      dsr[i] = bld1(rds, voff_ds[i], k0 * 4u);     // 0 beyond the split's last instance => dP = 0 there
-    }
-  }
-  __device__ inline void store(char* lds) {
-    const int c = d0 + 8 * Map::piece(tid);
-#pragma unroll
-    for (int i = 0; i < Map::NV; ++i) {
-      const int k = kbase + kt_loaded * TNB_KCH + Map::krow(tid, i);
-      const uint32_t idx = (uint32_t)k * (uint32_t)D + (uint32_t)c;
-      const float dsv = dsr[i];
-      float av[8], bv[8], oa[8], ob[8], w[8];
-      unpack8(ra4[i], av);
-      if (GATED) unpack8(rb4[i], bv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        oa[e] = gate_dp(gc, 0, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
-        ob[e] = GATED ? gate_dp(gc, 1, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
-      }
-      // the column sums (bias grads) are taken over the ROUNDED operand, i.e. exactly what the MFMA contracts
-      const float4 pa = pack8(oa);
-      char* dst = lds + Map::krow(tid, i) * PITCH + 16 * Map::piece(tid);
-      *reinterpret_cast<float4*>(dst) = pa;
-      float4 pb4 = zero4();
-      if (GATED) { pb4 = pack8(ob); *reinterpret_cast<float4*>(dst + DT * 2) = pb4; }
-      if (do_sum) {
-        float ra_[8], rb_[8];
-        unpack8(pa, ra_);
-        unpack8(pb4, rb_);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { cs_a[e] += ra_[e]; cs_b[e] += rb_[e]; cs2[e] += dsv * w[e]; }
-      }
-    }
-  }
-};
-
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -748,9 +806,16 @@ __device__ inline void tn_mainloop(LA& la, LB& lb, int nk, char* lds, f32x16 (&a
     char* cur = lds + (kt & 1) * T::STAGE_BYTES;
     char* nxt = lds + ((kt + 1) & 1) * T::STAGE_BYTES;
     const bool more = kt + 1 < nk;
-    if (more) { la.load(kt + 1); lb.load(kt + 1); }
+#ifdef MMF_DIAG_NOLOAD        /* diagnostic builds (tools/diag_build.py): timing only, results are wrong */
+    const bool stage = false;
+#else
+    const bool stage = more;
+#endif
+    if (stage) { la.load(kt + 1); lb.load(kt + 1); }
+#ifndef MMF_DIAG_NOMFMA
     tn_compute_chunk<T>(cur, cur + T::A_BYTES, acc, wm, wn, lane);
-    if (more) { la.store(nxt); lb.store(nxt + T::A_BYTES); }
+#endif
+    if (stage) { la.store(nxt); lb.store(nxt + T::A_BYTES); }
     __syncthreads();
   }
 }
@@ -786,29 +851,6 @@ __device__ inline void tnb_store(const TnBfProblem& q, int split, int tn, f32x16
   });
 }
 
-template <class T, bool GATED>
-__device__ inline void tnb_gate_tile(const TnBfParams& p, const TnBfProblem& q, LoadTPlain<T::BN, T::NT, T::B_PITCH>& lb,
-                                     int split, int tm, int tn, int kbase, int kmax, int nk, bool do_sum, char* lds) {
-  using LA = LoadTGate<T::BM, T::NT, T::A_PITCH, GATED>;
-  constexpr int DT = LA::DT;
-  const int D = p.g.D, d0 = tm * DT;
-  LA la;
-  la.init(p.g, d0, kbase, kmax, do_sum);
-  f32x16 acc[T::MB][T::NB];
-  tn_mainloop<T>(la, lb, nk, lds, acc);
-  float* fl = reinterpret_cast<float*>(lds);
-  tnb_store<T>(q, split, tn, acc, fl, [&](int r) {
-    const int half = r / DT, d = d0 + r - half * DT;
-    return d < D ? half * D + d : -1;
-  });
-  if (do_sum) {
-    float* cs = q.colsum + (size_t)split * q.colsum_stride;
-    colsum8_reduce_store<DT, T::NT>(fl, la.cs_a, cs, d0, D);
-    if (GATED) colsum8_reduce_store<DT, T::NT>(fl, la.cs_b, cs + D, d0, D);
-    if (q.colsum2) colsum8_reduce_store<DT, T::NT>(fl, la.cs2, q.colsum2 + (size_t)split * q.colsum2_stride, d0, D);
-  }
-}
-
 template <class T>
 __global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
   extern __shared__ __align__(16) char ldsb[];
@@ -825,22 +867,22 @@ __global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
   const int kmax = (int)((kb64 + p.k_per_split) < p.K ? (kb64 + p.k_per_split) : p.K);
   const int nk = (kmax - kbase + TNB_KCH - 1) / TNB_KCH;
   const bool do_sum = tn == 0 && q.colsum != nullptr;
+  BST_BEGIN();
 
   LoadTPlain<T::BN, T::NT, T::B_PITCH> lb;
   lb.init(q.B, q.ldb, tn * T::BN, q.Ncols, kbase, kmax, false);
-  if (q.kind == TN_A_PLAIN) {
+  {
     LoadTPlain<T::BM, T::NT, T::A_PITCH> la;
     la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
     f32x16 acc[T::MB][T::NB];
     tn_mainloop<T>(la, lb, nk, ldsb, acc);
+    BST_MARK(BST_TN, 1);
     float* fl = reinterpret_cast<float*>(ldsb);
     tnb_store<T>(q, split, tn, acc, fl, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
     if (do_sum) colsum8_reduce_store<T::BM, T::NT>(fl, la.cs, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
-  } else if (p.g.gated) {
-    tnb_gate_tile<T, true>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, ldsb);
-  } else {
-    tnb_gate_tile<T, false>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, ldsb);
   }
+  BST_MARK(BST_TN, 2);
+  BST_COUNT(BST_TN);
 }
 
 int tn_bf16_splits(int64_t K, int total_tiles) {
@@ -858,14 +900,8 @@ int launch_tn_bf16(TnBfParams p, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < p.nprob; ++i) {
     TnBfProblem& q = p.prob[i];
-    if (q.Ncols % 8 != 0 || q.ldb % 8 != 0 || q.M % 8 != 0) return MMF_ERR_SHAPE;
-    if (q.kind == TN_A_PLAIN && q.lda % 8 != 0) return MMF_ERR_SHAPE;
-    if (q.kind == TN_A_GATE) {
-      const int dt = p.g.gated ? T::BM / 2 : T::BM;
-      q.tiles_m = (p.g.D + dt - 1) / dt;
-    } else {
-      q.tiles_m = (q.M + T::BM - 1) / T::BM;
-    }
+    if (q.Ncols % 8 != 0 || q.ldb % 8 != 0 || q.M % 8 != 0 || q.lda % 8 != 0) return MMF_ERR_SHAPE;
+    q.tiles_m = (q.M + T::BM - 1) / T::BM;
     q.tiles_n = (q.Ncols + T::BN - 1) / T::BN;
     q.block_begin = blocks;
     blocks += q.tiles_m * q.tiles_n;

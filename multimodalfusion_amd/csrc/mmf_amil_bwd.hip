@@ -535,6 +535,37 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams p) {
     }
     return;
   }
+  if (s.tall) {      // many splits, short rows (per-row-tile partials): 16 column quads x 16 split groups per block
+    __shared__ __align__(16) float part[16][64];
+    const int cq = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int j = (b - s.block_begin) * 64 + 4 * cq;
+    float4 acc = zero4();
+    if (j < s.len) {
+      const float* in = s.in + j;
+      int k = grp;
+      for (; k + 7 * 16 < s.nsplit; k += 8 * 16) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld4(in + (size_t)(k + 16 * u) * s.stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; k < s.nsplit; k += 16) {
+        float4 v = ld4(in + (size_t)k * s.stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    st4(&part[grp][4 * cq], acc);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
+      const int c = (b - s.block_begin) * 64 + threadIdx.x;
+      if (c < s.len) s.out[c] = t;
+    }
+    return;
+  }
   const int j = ((b - s.block_begin) * 256 + threadIdx.x) * 4;
   if (j >= s.len) return;
   if ((s.len & 3) == 0 && (s.stride & 3) == 0) {
@@ -697,8 +728,10 @@ int launch_tn(TnParams p, hipStream_t st) {
 int launch_reduce(ReduceParams p, hipStream_t st) {
   int blocks = 0;
   for (int i = 0; i < p.nseg; ++i) {
-    p.seg[i].block_begin = blocks;
-    blocks += (p.seg[i].len + 1023) / 1024;
+    ReduceSeg& s = p.seg[i];
+    s.tall = s.nsplit >= 64 && s.len >= 4 && (s.len & 3) == 0 && (s.stride & 3) == 0;
+    s.block_begin = blocks;
+    blocks += s.tall ? (s.len + 63) / 64 : (s.len + 1023) / 1024;
   }
   if (blocks == 0) return MMF_OK;
   { ProfScope ps("reduce_kernel", st); hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(256), 0, st, p); }

@@ -122,9 +122,9 @@ static int check_desc(const mmf_amil_desc* d) {
 
 // ---- bf16-storage path (mmf_bf16.h) ----------------------------------------------------------
 struct AmilWsBf {
-  bf16_t *w1, *wab, *wabT, *h, *a, *b, *du;
-  float *s_part, *partials, *stats, *p, *ds, *dbc_part;
-  float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
+  bf16_t *w1, *wab, *wabT, *h, *a, *b, *du, *dP;
+  float *s_part, *partials, *stats, *p, *ds, *dbc_part, *dwc_part;
+  float *slab_w1, *slab_wab, *cs_b1, *cs_bab;
   int parts, groups, splits, k_per_split, mstk, dbc_cap;
   size_t bytes;
 };
@@ -144,8 +144,7 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   w.groups = pool_groups(N);
   w.mstk = gated ? 2 * D : D;
   const int td = TNB_TILE;
-  const int gate_dt = gated ? td / 2 : td;
-  const int tiles = ((H + td - 1) / td) * ((L + td - 1) / td) + ((D + gate_dt - 1) / gate_dt) * ((H + td - 1) / td);
+  const int tiles = ((H + td - 1) / td) * ((L + td - 1) / td) + ((w.mstk + td - 1) / td) * ((H + td - 1) / td);
   w.splits = tn_bf16_splits(N, tiles);
   const int64_t kps = (N + w.splits - 1) / w.splits;
   w.k_per_split = (int)((kps + TNB_KCH - 1) / TNB_KCH * TNB_KCH);
@@ -157,17 +156,18 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   w.a = take16((size_t)N * D);
   w.b = take16(gated ? (size_t)N * D : 0);
   w.du = take16((size_t)N * H);
+  w.dP = take16((size_t)N * w.mstk);
   w.s_part = take32((size_t)w.parts * N);
   w.partials = take32((size_t)w.groups * (2 + H));
   w.stats = take32(4);
   w.p = take32((size_t)N);
   w.ds = take32((size_t)N);
   w.dbc_part = take32((size_t)w.dbc_cap);
+  w.dwc_part = take32((size_t)w.dbc_cap * D);
   w.slab_w1 = take32((size_t)w.splits * H * L);
   w.slab_wab = take32((size_t)w.splits * w.mstk * H);
   w.cs_b1 = take32((size_t)w.splits * H);
   w.cs_bab = take32((size_t)w.splits * w.mstk);
-  w.cs_wc = take32((size_t)w.splits * D);
   w.bytes = off;
   return w;
 }
@@ -329,10 +329,10 @@ int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* works
   };
   cvt(d->W1, w.w1, d->H, d->L, d->L, 0, 0);
   cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, 0);
-  cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, 1);
+  cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, d->gated ? 2 : 1);     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
   if (d->gated) {
     cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
-    cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, d->D, 1);
+    cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
   }
   if (int e = launch_cvt_bf16(cp, st)) return e;
 
@@ -379,22 +379,22 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* work
   dp.g = gc; dp.WabT = w.wabT; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
   dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
-  dp.p_out = w.p; dp.ds_out = w.ds; dp.dbc_part = w.dbc_part;
+  dp.p_out = w.p; dp.ds_out = w.ds; dp.dbc_part = w.dbc_part; dp.dP = w.dP; dp.dwc_part = w.dwc_part;
   if (int e = launch_dh_bf16(dp, st)) return e;
   const int ntn = d->H / 256;
 
   TnBfParams tp{};
-  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc;
+  tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split;
   TnBfProblem& q1 = tp.prob[0];   // dW1[H x L] = du^T . x ; db1 = colsum(du)
-  q1.kind = TN_A_PLAIN; q1.A = w.du; q1.lda = d->H; q1.M = d->H;
+  q1.A = w.du; q1.lda = d->H; q1.M = d->H;
   q1.B = x; q1.ldb = d->L; q1.Ncols = d->L;
   q1.out = w.slab_w1; q1.split_stride = (size_t)d->H * d->L; q1.ldc = d->L;
-  q1.colsum = w.cs_b1; q1.colsum_stride = d->H; q1.colsum2 = nullptr; q1.colsum2_stride = 0;
-  TnBfProblem& q2 = tp.prob[1];   // dWab[(2)D x H] = dP^T . h ; (dba|dbb) = colsum(dP) ; dWc = colsum(ds.a_d.b_d)
-  q2.kind = TN_A_GATE; q2.A = nullptr; q2.lda = 0; q2.M = w.mstk;
+  q1.colsum = w.cs_b1; q1.colsum_stride = d->H;
+  TnBfProblem& q2 = tp.prob[1];   // dWab[(2)D x H] = dP^T . h ; (dba|dbb) = colsum(dP)
+  q2.A = w.dP; q2.lda = w.mstk; q2.M = w.mstk;
   q2.B = w.h; q2.ldb = d->H; q2.Ncols = d->H;
   q2.out = w.slab_wab; q2.split_stride = (size_t)w.mstk * d->H; q2.ldc = d->H;
-  q2.colsum = w.cs_bab; q2.colsum_stride = w.mstk; q2.colsum2 = w.cs_wc; q2.colsum2_stride = d->D;
+  q2.colsum = w.cs_bab; q2.colsum_stride = w.mstk;
   if (int e = launch_tn_bf16(tp, st)) return e;
 
   ReduceParams rp{};
@@ -408,7 +408,7 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* work
   seg(w.cs_b1, g->db1, d->H, w.splits, d->H);
   seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
   if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
-  seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
+  seg(w.dwc_part, g->dWc, d->D, dh_bf16_tiles_used(d->N, ntn), d->D);
   seg(w.dbc_part, g->dbc, 1, dh_bf16_tiles_used(d->N, ntn), 1);
   rp.nseg = n;
   return launch_reduce(rp, st);
@@ -474,9 +474,9 @@ int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nse
   if (int e = launch_tn(tp, st)) return e;
   if (splits > 1) {
     ReduceParams rp{};
-    rp.seg[0] = ReduceSeg{slab, dW, N * K, splits, (size_t)N * K, 0};
+    rp.seg[0] = ReduceSeg{slab, dW, N * K, splits, (size_t)N * K, 0, 0};
     rp.nseg = 1;
-    if (db) { rp.seg[1] = ReduceSeg{cs, db, N, splits, (size_t)N, 0}; rp.nseg = 2; }
+    if (db) { rp.seg[1] = ReduceSeg{cs, db, N, splits, (size_t)N, 0, 0}; rp.nseg = 2; }
     if (int e = launch_reduce(rp, st)) return e;
   }
   if (dx) {
@@ -591,9 +591,12 @@ int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t 
   return launch_kron_bwd(p, static_cast<hipStream_t>(stream));
 }
 
-/* diagnostic builds only (-DMMF_STAMPS): which = 0 forward TU, 1 backward TU; out8 = {load, mfma, store, barrier cycles, chunks} */
+/* diagnostic builds only (-DMMF_STAMPS): which = 0 forward TU, 1 backward TU; out8 = {load, mfma, store, barrier cycles, chunks};
+ * which = 2: bf16 TU, writes 32 values (4 kernels x {prologue, main loop, epilogue, -, -, -, -, waves}) */
 void mmf_debug_stamps(int which, unsigned long long* out8) {
-  if (which == 0) debug_stamps_fwd(out8); else debug_stamps_bwd(out8);
+  if (which == 0) debug_stamps_fwd(out8);
+  else if (which == 1) debug_stamps_bwd(out8);
+  else debug_stamps_bf16(out8);
 }
 
 static int xreduce_params(const mmf_xreduce_io* io, float drop_p, uint32_t seed, bool bwd, XReduceParams& p) {

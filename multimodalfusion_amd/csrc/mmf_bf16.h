@@ -38,7 +38,8 @@ __device__ inline float4 pack8(const float (&o)[8]) {
 __device__ inline uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2(a, b), pack2(c, d)); }
 #endif
 
-struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c])   or, transposed, dst[c][c0 + r] = bf16(src[r][c])
+struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  transpose 1: dst[c][c0 + r];
+                           // transpose 2: dst[c][c0 + 64 (r / 32) + r % 32]  (K-dh's interleaved [Wa-block | Wb-block] k order)
   const float* src; bf16_t* dst;
   int rows, cols, dst_ld, c0, transpose, block_begin;
 };
@@ -71,7 +72,9 @@ struct GateBwdBf {         // what the on-the-fly dP operand needs (bf16 a, b)
 
 struct DhBfParams {        // du = bf16((dP . Wab + p dM) . relu'(h) . scale_h), K-prep fused
   GateBwdBf g;
-  const bf16_t* WabT;      // [H x mstk] bf16, row n = column n of [Wa ; Wb]
+  const bf16_t* WabT;      // [H x mstk] bf16, row n = column n of Wa / Wb in K-dh's k order (gated: 32-dim blocks a, b, a, b ...)
+  bf16_t* dP;              // [N x mstk] out: [d pre-tanh | d pre-sigmoid], the TN kernel's operand
+  float* dwc_part;         // [mt_count x D] out: per-row-tile partial of dWc
   const float* dM; const bf16_t* h; bf16_t* du;
   int64_t N; int H; float scale_h;
   const float *A_raw, *stats, *Mpool, *gA;
@@ -80,18 +83,15 @@ struct DhBfParams {        // du = bf16((dP . Wab + p dM) . relu'(h) . scale_h),
 };
 
 struct TnBfProblem {       // C[M x Ncols] = A^T . B over one K split; A, B are bf16 [K x *]
-  int kind;                // TN_A_PLAIN / TN_A_GATE
   const bf16_t* A; int lda; int M;
   const bf16_t* B; int ldb; int Ncols;
   float* out; size_t split_stride; int ldc;
-  float* colsum; size_t colsum_stride;
-  float* colsum2; size_t colsum2_stride;
+  float* colsum; size_t colsum_stride;   // per split: column sums of A (bias grads), length M; null = skip
   int tiles_m, tiles_n, block_begin;
 };
 struct TnBfParams {
   TnBfProblem prob[2]; int nprob;
   int64_t K; int splits, k_per_split, total_tiles;
-  GateBwdBf g;
 };
 
 constexpr int TNB_KCH = 64;   // instances per staged chunk of the bf16 TN kernel
@@ -107,5 +107,6 @@ int dh_bf16_tiles_used(int64_t N, int ntn);     // dbc partials launch_dh_bf16 w
 int launch_dh_bf16(DhBfParams p, hipStream_t st);
 int tn_bf16_splits(int64_t K, int total_tiles);
 int launch_tn_bf16(TnBfParams p, hipStream_t st);
+void debug_stamps_bf16(unsigned long long* out32);
 
 }  // namespace mmf

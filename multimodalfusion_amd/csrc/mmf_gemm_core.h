@@ -283,7 +283,9 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
     }
     if (s % PER_Q == 0) hook(s / PER_Q);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef MMF_DIAG_NOMFMA      /* diagnostic builds (tools/diag_build.py): timing only, results are wrong */
     mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -338,6 +340,9 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     MMF_STAMP(t1);
     compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int q) {
       if (!more) return;
+#ifdef MMF_DIAG_NOLOAD
+      return;
+#endif
       if (q == 0) la.load(kt + 1);
       else if (q == 1) lb.load(kt + 1);
       else if (q == 2) la.store(nxt);

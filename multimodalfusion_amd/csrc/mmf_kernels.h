@@ -147,7 +147,7 @@ struct NnParams {          // C[M x N] = A[M x K] . B[K x N]   (plain; radio: dh
   int mt_count, nt_count;
 };
 
-struct ReduceSeg { const float* in; float* out; int len; int nsplit; size_t stride; int block_begin; };
+struct ReduceSeg { const float* in; float* out; int len; int nsplit; size_t stride; int block_begin; int tall; };
 struct ReduceParams { ReduceSeg seg[12]; int nseg; };
 
 int launch_linear(LinearParams p, hipStream_t st);

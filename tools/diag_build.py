@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic (timing-only, WRONG results) builds of the library, to split a kernel's time into its phases:
+
+    python tools/diag_build.py            # -> multimodalfusion_amd/_diag/libmmf_{noload,nomfma}.so
+    MMF_LIB_PATH=multimodalfusion_amd/_diag/libmmf_noload.so python bench.py --no-cpu-baseline ...
+
+noload: the main loops stage nothing after the first chunk (MFMA + LDS reads + epilogue only)
+nomfma: the main loops issue no MFMA (global loads + LDS writes + barriers + epilogue only)
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multimodalfusion_amd import build as B   # noqa: E402
+
+VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
+            "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"]}
+
+
+def main():
+    out_dir = os.path.join(B.HERE, "_diag")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, flags in VARIANTS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
+        objdir = os.path.join(B.OBJ, "diag_" + name)
+        os.makedirs(objdir, exist_ok=True)
+        jobs = []
+        objs = []
+        for s in B.SOURCES:
+            obj = os.path.join(objdir, s.replace(".hip", ".o"))
+            objs.append(obj)
+            jobs.append([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj])
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
+                if r.returncode != 0:
+                    raise SystemExit(r.stderr[-3000:])
+        lib = os.path.join(out_dir, f"libmmf_{name}.so")
+        subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+        print(lib)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,25 @@
+"""Diagnostic (stamps build: python tools/diag_build.py stamps): per-kernel phase cycles of the bf16 path.
+    MMF_LIB_PATH=multimodalfusion_amd/_diag/libmmf_stamps.so python tools/stamps_bf16.py [N]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from multimodalfusion_amd import _lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+dev = torch.device("cuda", 0)
+model = bench.build_model(dev, False)
+x = torch.randn(N, 1024, device=dev).to(torch.bfloat16)
+step = bench.make_step(model, x, dev)
+for _ in range(3): step()
+torch.cuda.synchronize()
+buf = (C.c_uint64 * 32)()
+_lib.lib().mmf_debug_stamps(2, buf)
+R = 10
+for _ in range(R): step()
+torch.cuda.synchronize()
+_lib.lib().mmf_debug_stamps(2, buf)
+for k, name in enumerate(["linear", "gate", "dh", "tn"]):
+    v = [int(t) for t in buf[8 * k:8 * k + 8]]
+    w = max(v[7], 1)
+    print(f"{name:7s} waves/launch {v[7] // R:6d}  per wave cycles (100 MHz s_memtime ticks x24 ~ shader clk): "
+          f"prologue {v[0] / w:9.0f}  mainloop {v[1] / w:9.0f}  epilogue {v[2] / w:9.0f}")
