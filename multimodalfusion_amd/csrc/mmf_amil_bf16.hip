@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "mmf_gemm_core.h"
+#include "mmf_gemm_dma.h"
 #include "mmf_bf16.h"
 
 namespace mmf {
@@ -22,9 +23,14 @@ namespace mmf {
 // {prologue, main loop, epilogue, -, -, -, -, waves}.  The shipped library contains none of this.
 #ifdef MMF_STAMPS
 static __device__ unsigned long long g_bst[32];
-#define BST_BEGIN() unsigned long long bst_prev = stamp_now(), bst_t
+__device__ inline unsigned long long real_now() {      // constant 100 MHz counter: calibrates the shader clock
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define BST_BEGIN() unsigned long long bst_real = real_now(), bst_prev = stamp_now(), bst_t
 #define BST_MARK(k, slot) do { bst_t = stamp_now(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_bst[8 * (k) + (slot)], bst_t - bst_prev); bst_prev = bst_t; } while (0)
-#define BST_COUNT(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_bst[8 * (k) + 7], 1ull); } while (0)
+#define BST_COUNT(k) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_bst[8 * (k) + 7], 1ull); atomicAdd(&g_bst[8 * (k) + 6], real_now() - bst_real); } } while (0)
 #else
 #define BST_BEGIN()
 #define BST_MARK(k, slot)
@@ -95,21 +101,28 @@ static inline int pick_bm(int64_t rows, int ntn) {
 // =============================================================================================
 // K-lin : h = bf16(drop(relu(x.W1^T + b1)))
 // =============================================================================================
+// LDS-DMA main loop (mmf_gemm_dma.h).  A register-staged version of this kernel on the fp32 core measured the same
+// (91 vs 94 us at 100k rows): the kernel is bound by the per-CU operand delivery (x from HBM plus the W1 tile re-read
+// from L2 by every row tile) and by its un-overlapped epilogue, not by the staging method (profiles/r01/README.md).
+using TileS128 = TileS<128, 256, 2, 4>;
+using TileS256 = TileS<256, 256, 2, 4, 2>;      // two stages of 64 KB: half the L2 re-reads of the weight tile
+
 template <class T>
-__global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
-  extern __shared__ __align__(16) float lds[];
+__global__ __launch_bounds__(T::NT) void linear_bf16_dma_kernel(LinearBfParams p) {
+  extern __shared__ __align__(16) char ldsc[];
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
   BST_BEGIN();
-  LoadK<T::BM, T::NT> la;
-  la.init(reinterpret_cast<const float*>(p.x), p.K / 2, row0, (int)p.M);
-  LoadK<T::BN, T::NT> lb;
-  lb.init(reinterpret_cast<const float*>(p.w), p.K / 2, col0, p.N);
+  DmaK<T::BM, T::NT> la;
+  la.init(p.x, p.K, row0, (int)p.M);
+  DmaK<T::BN, T::NT> lb;
+  lb.init(p.w, p.K, col0, p.N);
   f32x16 acc[T::MB][T::NB];
   BST_MARK(BST_LIN, 0);
-  gemm_mainloop<T>(la, lb, p.K / 64, lds, acc);
+  gemm_mainloop_dma<T>(la, lb, p.K / 64, ldsc, acc);
   BST_MARK(BST_LIN, 1);
+  float* lds = reinterpret_cast<float*>(ldsc);
 
   const uint32_t thr = drop_threshold(p.drop_p);
   const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
@@ -120,6 +133,9 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
     const int col = col0 + epilogue_col<T>(nb);
     bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
   }
+#ifdef MMF_DIAG_NOEPI
+  if (p.drop_p == 12345.f)
+#endif
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
     const int col = col0 + c;
     if (col >= p.N) return;
@@ -135,6 +151,9 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_kernel(LinearBfParams p) {
         y[e] = fmaxf(y[e], 0.f);
         if (p.drop_p > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
+      #ifdef MMF_DIAG_NOSTORE
+      if (p.drop_p == 12345.f)
+#endif
       *reinterpret_cast<uint2*>(p.y + (size_t)row * p.N + col) = pack4(y[0], y[1], y[2], y[3]);
     }
   });
@@ -147,13 +166,13 @@ int launch_linear_bf16(LinearBfParams p, hipStream_t st) {
   if (p.M <= 0) return MMF_OK;
   p.nt_count = p.N / 256;
   if (pick_bm(p.M, p.nt_count) == 128) {
-    using T = TileB128;
+    using T = TileS128;
     p.mt_count = (int)((p.M + T::BM - 1) / T::BM);
-    return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
+    return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_dma_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
   }
-  using T = TileB256;
+  using T = TileS256;
   p.mt_count = (int)((p.M + T::BM - 1) / T::BM);
-  return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
+  return launch_tiled_b<T>("linear_bf16_kernel", linear_bf16_dma_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), T::LDS_BYTES, st);
 }
 
 // =============================================================================================
@@ -855,7 +874,15 @@ template <class T>
 __global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
   extern __shared__ __align__(16) char ldsb[];
   const int b = blockIdx.x;
-  const int split = b / p.total_tiles, tg = b - split * p.total_tiles;
+  int split, tg;
+  if (p.xcd_map) {       // blocks b, b+8, ... share an XCD (round-robin dispatch): all tiles of one K split on one XCD,
+    const int xcd = b & 7, idx = b >> 3;   // so du / h / dP rows are fetched from HBM once and re-read through that L2
+    split = xcd + 8 * (idx / p.total_tiles);
+    tg = idx % p.total_tiles;
+  } else {
+    split = b / p.total_tiles;
+    tg = b - split * p.total_tiles;
+  }
   int pi = 0;
   for (int i = 1; i < p.nprob; ++i)
     if (tg >= p.prob[i].block_begin) pi = i;
@@ -888,6 +915,7 @@ __global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
 int tn_bf16_splits(int64_t K, int total_tiles) {
   static const int env = getenv("MMF_BF16_TN_SPLITS") ? atoi(getenv("MMF_BF16_TN_SPLITS")) : 0;   // tuning override
   int splits = 256 / (total_tiles > 0 ? total_tiles : 1);
+  if (splits >= 8) splits &= ~7;           // whole splits per XCD (launch_tn_bf16's block map)
   if (env > 0) splits = env;
   const int64_t max_splits = (K + 255) / 256;
   if (splits > max_splits) splits = (int)max_splits;
@@ -908,6 +936,8 @@ int launch_tn_bf16(TnBfParams p, hipStream_t st) {
   }
   if (blocks == 0) return MMF_OK;
   p.total_tiles = blocks;
+  static const int env_xcd = getenv("MMF_BF16_TN_XCD") ? atoi(getenv("MMF_BF16_TN_XCD")) : 1;   // tuning override
+  p.xcd_map = env_xcd && p.splits % 8 == 0;
   return launch_tiled_b<T>("tn_bf16_kernel", tn_bf16_kernel<T>, p, p.splits * blocks, T::LDS_BYTES, st);
 }
 

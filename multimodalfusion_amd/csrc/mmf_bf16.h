@@ -91,7 +91,7 @@ struct TnBfProblem {       // C[M x Ncols] = A^T . B over one K split; A, B are 
 };
 struct TnBfParams {
   TnBfProblem prob[2]; int nprob;
-  int64_t K; int splits, k_per_split, total_tiles;
+  int64_t K; int splits, k_per_split, total_tiles, xcd_map;
 };
 
 constexpr int TNB_KCH = 64;   // instances per staged chunk of the bf16 TN kernel

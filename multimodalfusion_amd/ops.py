@@ -271,8 +271,6 @@ class DenseFn(torch.autograd.Function):
         B, K = x.shape
         N = W.shape[0]
         dpre = torch.empty_like(y)
-        if ctx.bf16 and ctx.needs_input_grad[0]:
-            raise _lib.MmfError("a bf16 bag is a leaf: no input gradient on the bf16 path")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W)
         db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None

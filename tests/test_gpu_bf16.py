@@ -134,3 +134,39 @@ def test_bf16_constant_column_gives_bias_gradient(monkeypatch):
     res = run_path_hip_bf16(m, monkeypatch, xq)
     dW1, db1 = res["grads"]["attention_net_WSI.0.weight"], res["grads"]["attention_net_WSI.0.bias"]
     np.testing.assert_allclose(dW1[:, 17], db1, rtol=1e-4, atol=1e-7)
+
+
+def test_mm_with_bf16_path_bag_tracks_the_fp32_run():
+    """BASELINE config 5 shape: the multimodal head with the path bag in bf16 storage (radio / omic stay fp32).
+    Same weights and inputs through the fp32 kernels and through the bf16 path kernels: the difference is bf16
+    quantisation of the path branch only."""
+    from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    from test_gpu_path import _t
+    m = dict(fusion="concat", mode="radio_path_omic", Np=3000, nr=64, G=80, gate_path=True, gate_radio=True, K=4,
+             seed=77, x_seed=78, y=2, c=0, alpha=0.0, bias_std=0.02)
+    sd, xs, xp, xo = cases.mm_inputs(m)
+    out = {}
+    for tag in ("f32", "bf16"):
+        model = _load(MM_MIL_Attention_fc_surv(input_dim=80, radio_fusion="concat", fusion="concat", gate=True,
+                                               gate_path=True, gate_omic=True, gate_radio=True, n_classes=4,
+                                               mode=m["mode"]), sd).eval()
+        kw = {k: _t(x) for k, x in zip(cases.MODS, xs)}
+        xpq = torch.as_tensor(xp).to(torch.bfloat16)
+        kw["path_features"] = xpq.to(DEV) if tag == "bf16" else xpq.to(torch.float32).to(DEV)
+        kw["genomic_features"] = _t(xo)
+        hz, S, Yh, A_raw = model(**kw)
+        loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([m["y"]], device=DEV), c=torch.tensor([0.0], device=DEV))
+        loss.backward()
+        out[tag] = dict(hz=hz.detach().cpu().numpy(), A={k: v.detach().cpu().numpy() for k, v in A_raw.items()},
+                        loss=float(loss.detach()), grads=_grads(model))
+    a, b = out["f32"], out["bf16"]
+    np.testing.assert_allclose(b["hz"], a["hz"], rtol=0, atol=1e-2)
+    assert abs(b["loss"] - a["loss"]) <= 3e-2
+    np.testing.assert_allclose(b["A"]["pathology"], a["A"]["pathology"], rtol=0, atol=3e-2)
+    np.testing.assert_allclose(b["A"]["radiology"], a["A"]["radiology"], rtol=0, atol=1e-5)   # radio branch is untouched
+    for k, g in a["grads"].items():
+        if k.endswith(ZERO_GRADS):
+            continue
+        err, nrm = float(np.linalg.norm(b["grads"][k] - g)), float(np.linalg.norm(g))
+        assert err <= 0.15 * nrm + 1e-6, (k, err, nrm)

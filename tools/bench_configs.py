@@ -1,5 +1,6 @@
 """Step times of the other BASELINE.json configs (parity-test cases, not the headline):
-   config 2: radio_attention_mil 4 x (512 x 1024) + omic MaxNet (B=128, Cox);  config 3: mm_attention_mil (50k path bag)."""
+   config 2: radio_attention_mil 4 x (512 x 1024) + omic MaxNet (B=128, Cox);  config 3: mm_attention_mil (50k path bag);
+   config 4: mm_attention_mil with a 100k x 1024 bf16 path bag (bf16-storage kernels)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -39,3 +40,12 @@ for fusion in ("concat", "tensor"):
         hz, S, _, _ = mm(**kw); nll(hazards=hz, S=S, Y=Y, c=c).backward()
     t = timeit(mm_step, n=20, w=3)
     print(f"mm_attention_mil ({fusion}) 50k path + 4x512 radio + omic[80]: {t:.3f} ms/step = {1e3/t:.0f} bags/s")
+# config 5: multimodal with a 100k bf16 path bag
+for fusion in ("concat", "tensor"):
+    mm = MM_MIL_Attention_fc_surv(input_dim=80, fusion=fusion, n_classes=4).to(dev).train()
+    kw = dict(rx); kw["path_features"] = torch.randn(100000, 1024, device=dev).to(torch.bfloat16); kw["genomic_features"] = torch.randn(80, device=dev)
+    def mm_step():
+        for p in mm.parameters(): p.grad = None
+        hz, S, _, _ = mm(**kw); nll(hazards=hz, S=S, Y=Y, c=c).backward()
+    t = timeit(mm_step, n=20, w=3)
+    print(f"mm_attention_mil ({fusion}) 100k bf16 path + 4x512 radio + omic[80]: {t:.3f} ms/step = {1e3/t:.0f} bags/s")

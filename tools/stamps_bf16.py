@@ -21,5 +21,7 @@ _lib.lib().mmf_debug_stamps(2, buf)
 for k, name in enumerate(["linear", "gate", "dh", "tn"]):
     v = [int(t) for t in buf[8 * k:8 * k + 8]]
     w = max(v[7], 1)
-    print(f"{name:7s} waves/launch {v[7] // R:6d}  per wave cycles (100 MHz s_memtime ticks x24 ~ shader clk): "
-          f"prologue {v[0] / w:9.0f}  mainloop {v[1] / w:9.0f}  epilogue {v[2] / w:9.0f}")
+    tot = v[0] + v[1] + v[2]
+    mhz = tot / max(v[6], 1) * 100.0            # shader cycles per 100 MHz tick
+    print(f"{name:7s} waves/launch {v[7] // R:6d}  per wave shader cycles: prologue {v[0] / w:9.0f}  mainloop {v[1] / w:9.0f}  "
+          f"epilogue {v[2] / w:9.0f}   wave life {v[6] / w / 100.0:7.1f} us  (clock {mhz:6.0f} MHz)")
