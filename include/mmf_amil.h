@@ -97,6 +97,20 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* desc, const uint16_t* x, void* w
                            const mmf_amil_grads* grads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Forward-only variants for the inference consumers of the path -- embedding export
+ * (pre_trained_feature.py:116-162: model(..., return_features=True) under no_grad), per-patient inference and
+ * attention heat-map scoring (utils/heatmap_utils.py:111-150,249-275: A_raw per bag / per 512-patch batch).
+ * Same results as mmf_amil[_bf16]_forward, but nothing is saved for a backward: the a / b activations are never
+ * written and the workspace is the small one returned here.  desc->p_h / p_att should be 0 (eval mode).
+ * ------------------------------------------------------------------------------------------- */
+size_t mmf_amil_infer_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated);
+int mmf_amil_infer(const mmf_amil_desc* desc, const float* x, void* workspace, size_t workspace_bytes,
+                   float* M, float* A_raw, void* stream);
+size_t mmf_amil_bf16_infer_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated);
+int mmf_amil_bf16_infer(const mmf_amil_desc* desc, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                        float* M, float* A_raw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense layer on MFMA:  y = dropout(act(concat_k(x_0..x_{nseg-1}) . W^T + bias))
  *   replaces torch.cat + nn.Linear of model_attention_mil_radio.py:80-82 (reduce_dim; the modality
  *   bags are never concatenated in memory) and the instance projections generally.

@@ -274,8 +274,10 @@ __global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
         }
         if (row < p.N && dok) {
           const size_t o = (size_t)row * p.D + d;
-          *reinterpret_cast<uint2*>(p.a + o) = pack4(av[0], av[1], av[2], av[3]);
-          if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pack4(bv[0], bv[1], bv[2], bv[3]);
+          if (p.a) {     // null in forward-only (inference) calls
+            *reinterpret_cast<uint2*>(p.a + o) = pack4(av[0], av[1], av[2], av[3]);
+            if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pack4(bv[0], bv[1], bv[2], bv[3]);
+          }
           const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
           const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
 #pragma unroll

@@ -186,8 +186,10 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
         }
         if (row < p.N && dok) {
           const size_t o = (size_t)row * p.D + d;
-          st4(p.a + o, make_float4(av[0], av[1], av[2], av[3]));
-          if constexpr (GATED) st4(p.b + o, make_float4(bv[0], bv[1], bv[2], bv[3]));
+          if (p.a) {     // null in forward-only (inference) calls: nothing is saved for a backward
+            st4(p.a + o, make_float4(av[0], av[1], av[2], av[3]));
+            if constexpr (GATED) st4(p.b + o, make_float4(bv[0], bv[1], bv[2], bv[3]));
+          }
           const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
           const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
 #pragma unroll

@@ -66,7 +66,7 @@ struct AmilWs {
   size_t bytes;
 };
 
-static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated) {
+static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool infer = false) {
   AmilWs w{};
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -87,11 +87,15 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated) {
   w.k_per_split = (int)((kps + KC - 1) / KC * KC);
   if (w.k_per_split < KC) w.k_per_split = KC;
   w.h = take((size_t)N * H);
-  w.a = take((size_t)N * D);
-  w.b = take(gated ? (size_t)N * D : 0);
   w.s_part = take((size_t)w.parts * N);
   w.partials = take((size_t)w.groups * (2 + H));
   w.stats = take(4);
+  if (infer) {            // forward-only: nothing is kept for a backward (a, b stay null: K-gate skips their stores)
+    w.bytes = off;
+    return w;
+  }
+  w.a = take((size_t)N * D);
+  w.b = take(gated ? (size_t)N * D : 0);
   w.p = take((size_t)N);
   w.ds = take((size_t)N);
   w.dbc_part = take(PREP_GROUPS);
@@ -129,7 +133,7 @@ struct AmilWsBf {
   size_t bytes;
 };
 
-static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated) {
+static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated, bool infer = false) {
   AmilWsBf w{};
   char* p = static_cast<char*>(base);
   size_t off = 0;
@@ -153,13 +157,17 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   w.wab = take16((size_t)w.mstk * H);
   w.wabT = take16((size_t)H * w.mstk);
   w.h = take16((size_t)N * H);
+  w.s_part = take32((size_t)w.parts * N);
+  w.partials = take32((size_t)w.groups * (2 + H));
+  w.stats = take32(4);
+  if (infer) {
+    w.bytes = off;
+    return w;
+  }
   w.a = take16((size_t)N * D);
   w.b = take16(gated ? (size_t)N * D : 0);
   w.du = take16((size_t)N * H);
   w.dP = take16((size_t)N * w.mstk);
-  w.s_part = take32((size_t)w.parts * N);
-  w.partials = take32((size_t)w.groups * (2 + H));
-  w.stats = take32(4);
   w.p = take32((size_t)N);
   w.ds = take32((size_t)N);
   w.dbc_part = take32((size_t)w.dbc_cap);
@@ -184,7 +192,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 3; }
+int mmf_abi_version(void) { return 4; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -203,13 +211,13 @@ size_t mmf_amil_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int3
   return carve(nullptr, N, L, H, D, gated).bytes;
 }
 
-int mmf_amil_forward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
-                     float* M, float* A_raw, void* stream) {
+static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                             float* M, float* A_raw, void* stream, bool infer) {
   if (int e = check_desc(d)) return e;
   if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
   if (!aligned16(x) || !aligned16(workspace) || !aligned16(d->W1) || !aligned16(d->Wa) || (d->gated && !aligned16(d->Wb)))
     return MMF_ERR_ALIGN;
-  AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated);
+  AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
@@ -231,6 +239,21 @@ int mmf_amil_forward(const mmf_amil_desc* d, const float* x, void* workspace, si
   pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = w.h; pp.N = d->N; pp.H = d->H;
   pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
   return launch_pool(pp, st);
+}
+
+int mmf_amil_forward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                     float* M, float* A_raw, void* stream) {
+  return amil_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, false);
+}
+
+size_t mmf_amil_infer_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated) {
+  if (N < 1) N = 1;
+  return carve(nullptr, N, L, H, D, gated, true).bytes;
+}
+
+int mmf_amil_infer(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                   float* M, float* A_raw, void* stream) {
+  return amil_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, true);
 }
 
 int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
@@ -313,12 +336,12 @@ size_t mmf_amil_bf16_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D,
   return carve_bf16(nullptr, N, L, H, D, gated).bytes;
 }
 
-int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
-                          float* M, float* A_raw, void* stream) {
+static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                                  float* M, float* A_raw, void* stream, bool infer) {
   if (int e = check_desc_bf16(d)) return e;
   if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
   if (!aligned16(x) || !aligned16(workspace)) return MMF_ERR_ALIGN;
-  AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated);
+  AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
@@ -329,10 +352,10 @@ int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* works
   };
   cvt(d->W1, w.w1, d->H, d->L, d->L, 0, 0);
   cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, 0);
-  cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, d->gated ? 2 : 1);     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
+  if (!infer) cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, d->gated ? 2 : 1);     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
   if (d->gated) {
     cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
-    cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
+    if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
   }
   if (int e = launch_cvt_bf16(cp, st)) return e;
 
@@ -356,6 +379,21 @@ int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* works
   pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
   pb.h = w.h;
   return launch_pool_bf16(pb, st);
+}
+
+int mmf_amil_bf16_forward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                          float* M, float* A_raw, void* stream) {
+  return amil_bf16_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, false);
+}
+
+size_t mmf_amil_bf16_infer_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated) {
+  if (N < 1) N = 1;
+  return carve_bf16(nullptr, N, L, H, D, gated, true).bytes;
+}
+
+int mmf_amil_bf16_infer(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                        float* M, float* A_raw, void* stream) {
+  return amil_bf16_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, true);
 }
 
 int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,

@@ -97,7 +97,36 @@ class AmilPoolFn(torch.autograd.Function):
         return dx, dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, None, None, None, None
 
 
+def amil_infer(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated):
+    """Forward-only attention stack (include/mmf_amil.h: mmf_amil[_bf16]_infer): nothing is saved for a backward."""
+    bf16 = x.dtype == torch.bfloat16
+    x = x.contiguous() if bf16 else _f32c(x)
+    W1, b1, Wa, ba, Wc, bc = map(_f32c, (W1, b1, Wa, ba, Wc, bc))
+    Wb, bb = _f32c(Wb), _f32c(bb)
+    if x.dim() != 2:
+        raise _lib.MmfError(f"bag must be [N x L], got {tuple(x.shape)}")
+    N, L = x.shape
+    H, D = W1.shape[0], Wa.shape[0]
+    if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D:
+        raise _lib.MmfError("attention stack shapes do not match the bag")
+    d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                 W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                 Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                 Wc=ptr(Wc), bc=ptr(bc), p_h=0.0, p_att=0.0, seed=0)
+    l = lib()
+    ws_fn, fn, name = ((l.mmf_amil_bf16_infer_workspace_bytes, l.mmf_amil_bf16_infer, "mmf_amil_bf16_infer") if bf16
+                       else (l.mmf_amil_infer_workspace_bytes, l.mmf_amil_infer, "mmf_amil_infer"))
+    nbytes = ws_fn(N, L, H, D, d.gated)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    M = torch.empty((1, H), dtype=torch.float32, device=x.device)
+    A_raw = torch.empty((1, N), dtype=torch.float32, device=x.device)
+    check(fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), stream_ptr()), name)
+    return M, A_raw
+
+
 def amil_pool(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h=0.0, p_att=0.0, seed=0):
+    if not torch.is_grad_enabled() and p_h == 0.0 and p_att == 0.0:
+        return amil_infer(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated)     # torch.no_grad() + eval: the inference consumers
     return AmilPoolFn.apply(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
 
 

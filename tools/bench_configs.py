@@ -49,3 +49,12 @@ for fusion in ("concat", "tensor"):
         hz, S, _, _ = mm(**kw); nll(hazards=hz, S=S, Y=Y, c=c).backward()
     t = timeit(mm_step, n=20, w=3)
     print(f"mm_attention_mil ({fusion}) 100k bf16 path + 4x512 radio + omic[80]: {t:.3f} ms/step = {1e3/t:.0f} bags/s")
+# forward-only (inference consumers, infer.py): eval + no_grad takes the no-save kernels
+from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+pm = MIL_Attention_fc_surv_path(n_classes=4).to(dev).eval()
+for n, dt in ((50000, torch.float32), (100000, torch.bfloat16), (512, torch.float32)):
+    xb = torch.randn(n, 1024, device=dev).to(dt)
+    def fwd():
+        with torch.no_grad(): pm(path_features=xb)
+    t = timeit(fwd, n=30, w=5)
+    print(f"path head forward-only {n} x 1024 {str(dt).split('.')[-1]}: {t:.3f} ms = {1e3/t:.0f} bags/s")
