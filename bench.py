@@ -169,14 +169,16 @@ def graph_leg(model, dev, steps, gen):
     return res
 
 
-def h2d_leg(model, N, dev, steps, warmup):
+def h2d_leg(model, N, dev, steps, warmup, bf16=False):
     """PCIe-inclusive rate (never `value`): every step takes a NEW bag from pinned host memory; (a) copied
     synchronously at the top of the step as the reference does (utils/core_utils.py:194-198), (b) staged by
     feed.DevicePrefetcher (side stream, 2 bags in flight) so the copy overlaps the previous bag's kernels."""
     import torch
     from multimodalfusion_amd.feed import DevicePrefetcher
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
-    host = [torch.randn(N, 1024).pin_memory() for _ in range(3)]
+    # bf16 storage: the bags sit in host memory as bf16 (as a bf16 .pt file loads), half the PCIe bytes
+    host = [(torch.randn(N, 1024).to(torch.bfloat16) if bf16 else torch.randn(N, 1024)).pin_memory() for _ in range(3)]
+    esz = 2 if bf16 else 4
     loss_fn = NLLSurvLoss(alpha=0.0)
     Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
 
@@ -204,8 +206,8 @@ def h2d_leg(model, N, dev, steps, warmup):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         res[name] = {"bags_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps}
-    res["bytes_per_bag"] = N * 1024 * 4
-    res["h2d_gbs_prefetch"] = N * 1024 * 4 * res["prefetch"]["bags_per_s"] / 1e9
+    res["bytes_per_bag"] = N * 1024 * esz
+    res["h2d_gbs_prefetch"] = N * 1024 * esz * res["prefetch"]["bags_per_s"] / 1e9
     return res
 
 
@@ -370,7 +372,7 @@ def main():
         if args.graph and world == 1:
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
         if args.h2d and world == 1:
-            out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup)
+            out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup, bf16)
         if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

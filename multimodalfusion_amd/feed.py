@@ -16,6 +16,29 @@ from collections import deque
 import torch
 
 
+def load_slide_bags(paths, pin: bool = True, dtype=None) -> torch.Tensor:
+    """One subject's pathology bag from its per-slide `.pt` files, as datasets/dataset_survival.py:359-366 builds it
+    (`torch.load` each slide, `torch.cat(dim=0)`), but assembled directly in ONE pinned host buffer: the slides are
+    read into their row ranges, so there is no pageable intermediate and the H2D copy can be asynchronous.
+    An empty list gives the reference's "missing" sentinel `torch.zeros((1, 1))` (dataset_survival.py:356-357).
+    `dtype` (e.g. torch.bfloat16) narrows while copying -- meant for bags already stored in that type on disk, where
+    it is a no-op; narrowing 200 MB of fp32 on the host costs more than the PCIe time it saves."""
+    if len(paths) == 0:
+        return torch.zeros((1, 1))
+    bags = [torch.load(p, map_location="cpu") for p in paths]
+    for b in bags:
+        if b.dim() != 2 or b.shape[1] != bags[0].shape[1]:
+            raise ValueError("slide bags must be [n_i x L] with one feature width")
+    dt = dtype or bags[0].dtype
+    out = torch.empty((sum(b.shape[0] for b in bags), bags[0].shape[1]), dtype=dt,
+                      pin_memory=bool(pin) and torch.cuda.is_available())
+    r = 0
+    for b in bags:
+        out[r:r + b.shape[0]].copy_(b)
+        r += b.shape[0]
+    return out
+
+
 def _pin(t: torch.Tensor) -> torch.Tensor:
     if not torch.is_tensor(t) or t.is_cuda:
         return t
@@ -23,8 +46,12 @@ def _pin(t: torch.Tensor) -> torch.Tensor:
 
 
 class DevicePrefetcher:
-    def __init__(self, loader, device=None, depth: int = 2):
+    def __init__(self, loader, device=None, depth: int = 2, path_dtype=None):
+        """path_dtype=torch.bfloat16 delivers the pathology bag in bf16, which selects the bf16-storage kernels
+        (include/mmf_amil.h: mmf_amil_bf16_*).  A bag that is already bf16 on the host crosses PCIe at half the
+        bytes; an fp32 bag is copied as it is and narrowed on the device, on the copy stream."""
         self.loader = loader
+        self.path_dtype = path_dtype
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.depth = max(1, int(depth))
         self.stream = torch.cuda.Stream(self.device)
@@ -36,7 +63,11 @@ class DevicePrefetcher:
         radio, path, genomic, label, event_time, c = batch
         with torch.cuda.stream(self.stream):
             move = lambda t: _pin(t).to(self.device, non_blocking=True) if torch.is_tensor(t) else t
-            out = ({k: move(v) for k, v in radio.items()}, move(path),
+            path_d = move(path)
+            if self.path_dtype is not None and torch.is_tensor(path_d) and path_d.dim() == 2 and path_d.shape[1] > 1 \
+                    and path_d.dtype != self.path_dtype:
+                path_d = path_d.to(self.path_dtype)          # on the copy stream, after the H2D of the fp32 bag
+            out = ({k: move(v) for k, v in radio.items()}, path_d,
                    move(genomic.float() if torch.is_tensor(genomic) else genomic), move(label), event_time, move(c))
             ev = torch.cuda.Event()
             ev.record(self.stream)

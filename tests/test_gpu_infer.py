@@ -98,3 +98,18 @@ def test_feature_export_loop_skips_missing_modalities():
     # the path embedding equals the oracle's pooled M
     hz, S, Yh, A_raw, M = tp.path_forward(tp.to_torch(sd, torch.float64, False), torch.as_tensor(gen.bag(1, 300)).double(), True, False, None)
     np.testing.assert_allclose(out[0][2].numpy(), M.numpy(), rtol=0, atol=1e-4)
+
+
+def test_prefetcher_delivers_bf16_bags():
+    """feed.DevicePrefetcher(path_dtype=bf16): fp32 host bags are narrowed on the device, bf16 host bags cross as they
+    are; either way the head sees exactly x.to(bf16) and takes the bf16-storage kernels."""
+    from multimodalfusion_amd.feed import DevicePrefetcher
+    model, _ = _path_model(seed=12)
+    x = torch.as_tensor(gen.bag(51, 900))
+    with torch.no_grad():
+        want = model(path_features=x.to(torch.bfloat16).to(DEV), attention_only=True)
+        for host in (x, x.to(torch.bfloat16)):
+            batches = [({}, host, torch.zeros(1, 1), torch.tensor([1]), None, torch.tensor([0.0]))] * 2
+            for b in DevicePrefetcher(batches, DEV, depth=2, path_dtype=torch.bfloat16):
+                assert b[1].dtype == torch.bfloat16 and b[1].is_cuda
+                assert torch.equal(model(path_features=b[1], attention_only=True), want)
