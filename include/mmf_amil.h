@@ -200,6 +200,40 @@ typedef struct mmf_xreduce_io {
 int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
 int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stage-2 building blocks: the embedding-level fusion models trained on the exported [B x 256] features
+ * (models/nll_models_pretrained.py:13-197, models/coxranking_models_pretrained.py:14-200) and their batched losses.
+ * ------------------------------------------------------------------------------------------- */
+/* y = dropout(act(BatchNorm1d(x) [+ res])), x / y / res: [B x F].  training != 0: batch statistics (biased variance),
+ * running_mean / running_var updated in place with `momentum` and the unbiased variance (torch semantics; B >= 2);
+ * training == 0: running statistics.  save_mean / save_invstd [F] are what backward reads.
+ * Replaces nn.BatchNorm1d (+ the ReLU / Dropout / residual add that follow it) in models/model_modules.py:5-49 and
+ * models/nll_models_pretrained.py:82-90. */
+int mmf_batchnorm_forward(const float* x, const float* res, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int32_t B, int32_t F, int32_t training,
+                          float eps, float momentum, int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                          float* y, float* save_mean, float* save_invstd, void* stream);
+int mmf_batchnorm_backward(const float* dy, const float* y, const float* x, const float* gamma,
+                           const float* save_mean, const float* save_invstd, int32_t B, int32_t F, int32_t training,
+                           int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                           float* dx, float* dres /* or NULL */, float* dgamma, float* dbeta, void* stream);
+/* Highway mix, models/model_modules.py:21-25: y = sigmoid(zg) * relu(zn) + (1 - sigmoid(zg)) * zl, elementwise over n. */
+int mmf_highway_mix_forward(const float* zg, const float* zn, const float* zl, int64_t n, float* y, void* stream);
+int mmf_highway_mix_backward(const float* dy, const float* zg, const float* zn, const float* zl, int64_t n,
+                             float* dzg, float* dzn, float* dzl, void* stream);
+/* ranking_loss, utils/loss_utils.py:58-101 (a Python loop over all pairs): loss = -(mean | sum) over comparable pairs of
+ * phi(risk_more - risk_less); phi 0 = sigmoid, 1 = relu; reduction 0 = mean, 1 = sum; 0 when no pair is comparable.
+ * times: device double[B] (event times, or the bin labels for RankingNLLSurvLoss, loss_utils.py:160).  Writes the loss
+ * and its gradient w.r.t. risks.  B >= 2. */
+int mmf_ranking_loss(const float* risks, const double* times, const float* c, int32_t B, int32_t phi, int32_t reduction,
+                     float* loss, float* d_risks, void* stream);
+/* logits [B x K] -> hazards = sigmoid, S = cumprod(1 - hazards), Y_hat = argmax, risk = -sum_k S
+ * (models/nll_models_pretrained.py:58-62,193-197).  K <= 32. */
+int mmf_hazards_forward(const float* logits, int32_t B, int32_t K, float* hazards, float* S, int64_t* Y_hat, float* risk,
+                        void* stream);
+int mmf_hazards_backward(const float* g_hazards, const float* g_S, const float* g_risk /* each may be NULL */,
+                         const float* hazards, int32_t B, int32_t K, float* dlogits, void* stream);
+
 /* Graph-replay-safe dropout.  By-value seeds are frozen into a captured hipGraph; with a device word registered here
  * every kernel adds *seed_dev to its dropout keys (effective seed = seed argument + *seed_dev, uint32 wrap), so a
  * graph whose first node increments that word draws fresh masks per replay.  NULL = off (default).  Process-wide. */

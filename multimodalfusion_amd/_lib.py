@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -101,6 +101,15 @@ SYMBOLS = {
     "mmf_abs_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_xreduce_forward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
     "mmf_xreduce_backward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
+    "mmf_batchnorm_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                                         C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4),
+    "mmf_batchnorm_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                          C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5),
+    "mmf_highway_mix_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    "mmf_highway_mix_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 4),
+    "mmf_ranking_loss": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p] * 3),
+    "mmf_hazards_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
+    "mmf_hazards_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mmf_set_device_seed": (None, [C.c_void_p]),
     "mmf_profile_enable": (None, [C.c_int]),
     "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),

@@ -192,7 +192,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 4; }
+int mmf_abi_version(void) { return 5; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -668,6 +668,58 @@ int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, 
   XReduceParams p;
   if (int e = xreduce_params(io, drop_p, seed, true, p)) return e;
   return launch_xreduce_bwd(p, static_cast<hipStream_t>(stream));
+}
+
+int mmf_batchnorm_forward(const float* x, const float* res, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int32_t B, int32_t F, int32_t training,
+                          float eps, float momentum, int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                          float* y, float* save_mean, float* save_invstd, void* stream) {
+  if (!x || !y || !save_mean || !save_invstd || B < 1 || F < 1) return MMF_ERR_ARG;
+  if (!training && (!running_mean || !running_var)) return MMF_ERR_ARG;
+  if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  BnParams p{x, res, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, B, F, training, act, eps, momentum,
+             make_drop(1, drop_p, seed, site)};
+  return launch_bn_fwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_batchnorm_backward(const float* dy, const float* y, const float* x, const float* gamma,
+                           const float* save_mean, const float* save_invstd, int32_t B, int32_t F, int32_t training,
+                           int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                           float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !y || !x || !save_mean || !save_invstd || !dx || B < 1 || F < 1) return MMF_ERR_ARG;
+  if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
+  BnBwdParams p{dy, y, x, gamma, save_mean, save_invstd, dx, dres, dgamma, dbeta, B, F, training, act,
+                make_drop(1, drop_p, seed, site)};
+  return launch_bn_bwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_highway_mix_forward(const float* zg, const float* zn, const float* zl, int64_t n, float* y, void* stream) {
+  if (!zg || !zn || !zl || !y || n < 1) return MMF_ERR_ARG;
+  HighwayParams p{zg, zn, zl, y, nullptr, nullptr, nullptr, nullptr, n};
+  return launch_highway_fwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_highway_mix_backward(const float* dy, const float* zg, const float* zn, const float* zl, int64_t n,
+                             float* dzg, float* dzn, float* dzl, void* stream) {
+  if (!dy || !zg || !zn || !zl || !dzg || !dzn || !dzl || n < 1) return MMF_ERR_ARG;
+  HighwayParams p{zg, zn, zl, nullptr, dy, dzg, dzn, dzl, n};
+  return launch_highway_bwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_ranking_loss(const float* risks, const double* times, const float* c, int32_t B, int32_t phi, int32_t reduction,
+                     float* loss, float* d_risks, void* stream) {
+  if (!risks || !times || !c || !loss || !d_risks) return MMF_ERR_ARG;
+  if (phi < 0 || phi > 1 || reduction < 0 || reduction > 1) return MMF_ERR_ARG;
+  RankParams p{risks, times, c, B, phi, reduction, loss, d_risks};
+  return launch_rank_loss(p, static_cast<hipStream_t>(stream));
+}
+int mmf_hazards_forward(const float* logits, int32_t B, int32_t K, float* hazards, float* S, int64_t* Y_hat, float* risk,
+                        void* stream) {
+  if (!logits || !hazards || !S) return MMF_ERR_ARG;
+  HazardParams p{logits, hazards, S, risk, Y_hat, nullptr, nullptr, nullptr, nullptr, B, K};
+  return launch_hazard_fwd(p, static_cast<hipStream_t>(stream));
+}
+int mmf_hazards_backward(const float* g_hazards, const float* g_S, const float* g_risk, const float* hazards,
+                         int32_t B, int32_t K, float* dlogits, void* stream) {
+  if (!hazards || !dlogits) return MMF_ERR_ARG;
+  HazardParams p{nullptr, const_cast<float*>(hazards), nullptr, nullptr, nullptr, g_hazards, g_S, g_risk, dlogits, B, K};
+  return launch_hazard_bwd(p, static_cast<hipStream_t>(stream));
 }
 
 /* Graph-replay-safe dropout: when a device pointer is set, every kernel adds *seed_dev to its dropout keys, so a

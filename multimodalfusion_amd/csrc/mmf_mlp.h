@@ -59,3 +59,47 @@ struct XReduceParams {
 int launch_xreduce_fwd(XReduceParams p, hipStream_t st);
 int launch_xreduce_bwd(XReduceParams p, hipStream_t st);
 }  // namespace mmf
+
+// ---- stage-2 (embedding-level) building blocks: SURVEY.md 8f row N3 --------------------------------------------
+namespace mmf {
+struct BnParams {            // y = drop(act(BatchNorm1d(x) [+ res]))      x, y: [B x F]
+  const float *x, *res, *gamma, *beta;
+  float *running_mean, *running_var;     // updated in training mode (momentum, unbiased variance), read in eval
+  float *y, *save_mean, *save_invstd;    // save_*: [F], what backward needs
+  int B, F, training, act;
+  float eps, momentum;
+  DropSpec drop;
+};
+struct BnBwdParams {
+  const float *dy, *y, *x, *gamma, *save_mean, *save_invstd;
+  float *dx, *dres, *dgamma, *dbeta;     // dres may be null
+  int B, F, training, act;
+  DropSpec drop;
+};
+struct HighwayParams {       // y = sigmoid(zg) * relu(zn) + (1 - sigmoid(zg)) * zl        all [n]
+  const float *zg, *zn, *zl;
+  float* y;
+  const float* dy;                       // backward
+  float *dzg, *dzn, *dzl;
+  int64_t n;
+};
+struct RankParams {          // loss = -mean|sum over comparable pairs of phi(risk_more - risk_less)
+  const float* risks; const double* times; const float* c;
+  int B, phi, reduction;                 // phi: 0 sigmoid, 1 relu; reduction: 0 mean, 1 sum
+  float *loss, *d_risks;
+};
+struct HazardParams {        // logits [B x K] -> hazards, S, Y_hat, risk = -sum_k S
+  const float* logits;
+  float *hazards, *S, *risk; int64_t* Y_hat;
+  const float *g_hazards, *g_S, *g_risk;  // backward (any may be null)
+  float* dlogits;
+  int B, K;
+};
+int launch_bn_fwd(BnParams p, hipStream_t st);
+int launch_bn_bwd(BnBwdParams p, hipStream_t st);
+int launch_highway_fwd(HighwayParams p, hipStream_t st);
+int launch_highway_bwd(HighwayParams p, hipStream_t st);
+int launch_rank_loss(RankParams p, hipStream_t st);
+int launch_hazard_fwd(HazardParams p, hipStream_t st);
+int launch_hazard_bwd(HazardParams p, hipStream_t st);
+}  // namespace mmf

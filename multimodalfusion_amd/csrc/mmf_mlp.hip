@@ -404,4 +404,211 @@ int launch_kron_bwd(KronParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+
+// =============================================================================================
+// Stage-2 building blocks: the embedding-level fusion models of
+// models/nll_models_pretrained.py / models/coxranking_models_pretrained.py work on [B x 256] batches (B = 32): every
+// op is latency-bound, so each is ONE small launch with its neighbours fused in.
+// =============================================================================================
+// BatchNorm1d (+ residual add, activation, dropout): one thread per feature, coalesced across features.
+//   replaces nn.BatchNorm1d inside Highway (models/model_modules.py:13-14,18-19,26), the FCNN blocks
+//   Linear-BatchNorm1d-ReLU-Dropout (models/nll_models_pretrained.py:82-90) and ResidualBlock (model_modules.py:29-49).
+__global__ __launch_bounds__(256) void bn_fwd_kernel(BnParams p) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= p.F) return;
+  float mean, invstd;
+  if (p.training) {
+    float s = 0.f;
+    for (int b = 0; b < p.B; ++b) s += p.x[(size_t)b * p.F + f];
+    mean = s / (float)p.B;
+    float v = 0.f;
+    for (int b = 0; b < p.B; ++b) { const float d = p.x[(size_t)b * p.F + f] - mean; v += d * d; }
+    const float var = v / (float)p.B;                       // biased: what normalises the batch
+    invstd = rsqrtf(var + p.eps);
+    if (p.running_mean) {
+      p.running_mean[f] = (1.f - p.momentum) * p.running_mean[f] + p.momentum * mean;
+      p.running_var[f] = (1.f - p.momentum) * p.running_var[f] + p.momentum * (v / (float)(p.B - 1));   // unbiased
+    }
+  } else {
+    mean = p.running_mean[f];
+    invstd = rsqrtf(p.running_var[f] + p.eps);
+  }
+  p.save_mean[f] = mean;
+  p.save_invstd[f] = invstd;
+  const float g = p.gamma ? p.gamma[f] : 1.f, be = p.beta ? p.beta[f] : 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    const size_t o = (size_t)b * p.F + f;
+    float v = (p.x[o] - mean) * invstd * g + be;
+    if (p.res) v += p.res[o];
+    p.y[o] = drop_fwd(act_fwd(v, p.act), p.drop, (uint32_t)o);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdParams p) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= p.F) return;
+  const float mean = p.save_mean[f], invstd = p.save_invstd[f], g = p.gamma ? p.gamma[f] : 1.f;
+  float sum_d = 0.f, sum_dx = 0.f;          // sum dpre, sum dpre * xhat
+  for (int b = 0; b < p.B; ++b) {
+    const size_t o = (size_t)b * p.F + f;
+    float dydy, y;
+    drop_bwd(p.y[o], p.drop, (uint32_t)o, dydy, y);
+    const float dpre = p.dy[o] * dydy * act_grad_from_y(y, p.act);
+    const float xhat = (p.x[o] - mean) * invstd;
+    sum_d += dpre;
+    sum_dx += dpre * xhat;
+    if (p.dres) p.dres[o] = dpre;
+  }
+  if (p.dgamma) p.dgamma[f] = sum_dx;
+  if (p.dbeta) p.dbeta[f] = sum_d;
+  const float invB = 1.0f / (float)p.B;
+  for (int b = 0; b < p.B; ++b) {
+    const size_t o = (size_t)b * p.F + f;
+    float dydy, y;
+    drop_bwd(p.y[o], p.drop, (uint32_t)o, dydy, y);
+    const float dpre = p.dy[o] * dydy * act_grad_from_y(y, p.act);
+    const float xhat = (p.x[o] - mean) * invstd;
+    p.dx[o] = p.training ? g * invstd * (dpre - invB * sum_d - xhat * invB * sum_dx) : g * invstd * dpre;
+  }
+}
+
+int launch_bn_fwd(BnParams p, hipStream_t st) {
+  if (p.B < 1 || p.F < 1 || (p.training && p.B < 2)) return MMF_ERR_SHAPE;    // torch: "Expected more than 1 value per channel"
+  { ProfScope ps("bn_fwd_kernel", st); hipLaunchKernelGGL(bn_fwd_kernel, dim3(cdiv(p.F, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+int launch_bn_bwd(BnBwdParams p, hipStream_t st) {
+  if (p.B < 1 || p.F < 1) return MMF_ERR_SHAPE;
+  { ProfScope ps("bn_bwd_kernel", st); hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(p.F, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// Highway mix (models/model_modules.py:21-25): x = gate * f(nonlinear) + (1 - gate) * linear, gate = sigmoid, f = relu
+__global__ __launch_bounds__(256) void highway_fwd_kernel(HighwayParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const float g = 1.0f / (1.0f + expf(-p.zg[i]));
+  p.y[i] = g * fmaxf(p.zn[i], 0.f) + (1.f - g) * p.zl[i];
+}
+__global__ __launch_bounds__(256) void highway_bwd_kernel(HighwayParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const float g = 1.0f / (1.0f + expf(-p.zg[i])), zn = p.zn[i], dy = p.dy[i];
+  p.dzg[i] = dy * (fmaxf(zn, 0.f) - p.zl[i]) * g * (1.f - g);
+  p.dzn[i] = zn > 0.f ? dy * g : 0.f;
+  p.dzl[i] = dy * (1.f - g);
+}
+int launch_highway_fwd(HighwayParams p, hipStream_t st) {
+  { ProfScope ps("highway_fwd_kernel", st); hipLaunchKernelGGL(highway_fwd_kernel, dim3(cdiv(p.n, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+int launch_highway_bwd(HighwayParams p, hipStream_t st) {
+  { ProfScope ps("highway_bwd_kernel", st); hipLaunchKernelGGL(highway_bwd_kernel, dim3(cdiv(p.n, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// Pairwise ranking loss (utils/loss_utils.py:58-101: a Python loop over all B(B-1)/2 pairs): one workgroup,
+// thread i owns sample i and walks all j.  Pair {a < b}: a more risky if t_a < t_b and event_a; else b more risky if
+// t_b < t_a and event_b; else not comparable.  loss = -(mean | sum) of phi(risk_more - risk_less); 0 if no pair.
+__global__ __launch_bounds__(256) void rank_loss_kernel(RankParams p) {
+  __shared__ float s_sum[256];
+  __shared__ int s_cnt[256];
+  const int tid = threadIdx.x;
+  float sum = 0.f;
+  int cnt = 0;
+  for (int i = tid; i < p.B; i += 256) {
+    float gi = 0.f;
+    const double ti = p.times[i];
+    const bool ei = (1.f - p.c[i]) != 0.f;
+    const float ri = p.risks[i];
+    for (int j = 0; j < p.B; ++j) {
+      if (j == i) continue;
+      const double tj = p.times[j];
+      const bool ej = (1.f - p.c[j]) != 0.f;
+      // index-ordered rule of the reference: a = min(i, j), b = max(i, j)
+      const bool i_is_a = i < j;
+      const double ta = i_is_a ? ti : tj, tb = i_is_a ? tj : ti;
+      const bool ea = i_is_a ? ei : ej, eb = i_is_a ? ej : ei;
+      int more;                                   // 0: a, 1: b, -1: not comparable
+      if (ta < tb && ea) more = 0;
+      else if (tb < ta && eb) more = 1;
+      else continue;
+      const bool i_more = (more == 0) == i_is_a;
+      const float r = i_more ? ri - p.risks[j] : p.risks[j] - ri;
+      float phi, dphi;
+      if (p.phi == 0) { phi = 1.0f / (1.0f + expf(-r)); dphi = phi * (1.f - phi); }
+      else { phi = fmaxf(r, 0.f); dphi = r > 0.f ? 1.f : 0.f; }
+      gi += i_more ? dphi : -dphi;
+      if (i_is_a) { sum += phi; ++cnt; }          // every unordered pair counted once
+    }
+    p.d_risks[i] = gi;                            // scaled below
+  }
+  s_sum[tid] = sum;
+  s_cnt[tid] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { s_sum[tid] += s_sum[tid + o]; s_cnt[tid] += s_cnt[tid + o]; }
+    __syncthreads();
+  }
+  const int n = s_cnt[0];
+  const float scale = n == 0 ? 0.f : (p.reduction == 0 ? -1.0f / (float)n : -1.0f);
+  if (tid == 0) p.loss[0] = n == 0 ? 0.f : s_sum[0] * scale;
+  for (int i = tid; i < p.B; i += 256) p.d_risks[i] *= scale;
+}
+int launch_rank_loss(RankParams p, hipStream_t st) {
+  if (p.B < 2) return MMF_ERR_SHAPE;              // the reference raises NotImplementedError for batch size 1
+  { ProfScope ps("rank_loss_kernel", st); hipLaunchKernelGGL(rank_loss_kernel, dim3(1), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+// logits -> hazards = sigmoid, S = cumprod(1 - hazards), Y_hat = argmax, risk = -sum S
+// (models/nll_models_pretrained.py:58-62,193-197); one thread per sample, K <= 32.
+__global__ __launch_bounds__(256) void hazard_fwd_kernel(HazardParams p) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= p.B) return;
+  float s = 1.f, rs = 0.f, best = -INFINITY;
+  int arg = 0;
+  for (int k = 0; k < p.K; ++k) {
+    const float z = p.logits[(size_t)b * p.K + k];
+    if (z > best) { best = z; arg = k; }
+    const float h = 1.0f / (1.0f + expf(-z));
+    s *= 1.f - h;
+    p.hazards[(size_t)b * p.K + k] = h;
+    p.S[(size_t)b * p.K + k] = s;
+    rs += s;
+  }
+  if (p.Y_hat) p.Y_hat[b] = arg;
+  if (p.risk) p.risk[b] = -rs;
+}
+__global__ __launch_bounds__(256) void hazard_bwd_kernel(HazardParams p) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= p.B) return;
+  float h[32];
+  for (int k = 0; k < p.K; ++k) h[k] = p.hazards[(size_t)b * p.K + k];
+  const float gr = p.g_risk ? p.g_risk[b] : 0.f;
+  for (int t = 0; t < p.K; ++t) {
+    // d S_j / d h_t = -prod_{u <= j, u != t} (1 - h_u) for j >= t   (no division: 1 - h_t may underflow)
+    float acc = 0.f, pre = 1.f;
+    for (int u = 0; u < t; ++u) pre *= 1.f - h[u];
+    float prod = pre;
+    for (int j = t; j < p.K; ++j) {
+      if (j > t) prod *= 1.f - h[j];
+      const float gS = (p.g_S ? p.g_S[(size_t)b * p.K + j] : 0.f) - gr;
+      acc -= gS * prod;
+    }
+    const float gh = (p.g_hazards ? p.g_hazards[(size_t)b * p.K + t] : 0.f) + acc;
+    p.dlogits[(size_t)b * p.K + t] = gh * h[t] * (1.f - h[t]);
+  }
+}
+int launch_hazard_fwd(HazardParams p, hipStream_t st) {
+  if (p.B < 1 || p.K < 1 || p.K > 32) return MMF_ERR_SHAPE;
+  { ProfScope ps("hazard_fwd_kernel", st); hipLaunchKernelGGL(hazard_fwd_kernel, dim3(cdiv(p.B, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+int launch_hazard_bwd(HazardParams p, hipStream_t st) {
+  if (p.B < 1 || p.K < 1 || p.K > 32) return MMF_ERR_SHAPE;
+  { ProfScope ps("hazard_bwd_kernel", st); hipLaunchKernelGGL(hazard_bwd_kernel, dim3(cdiv(p.B, 256)), dim3(256), 0, st, p); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 }  // namespace mmf

@@ -71,6 +71,84 @@ def snn_stack(fc_omic, x, training, seed=None):
     return f
 
 
+def _drop_args(module_training, p, seed):
+    from .. import ops
+    if not module_training:
+        return 0.0, 0
+    return p, (ops.next_dropout_seed() if seed is None else seed)
+
+
+class Highway(nn.Module):
+    """models/model_modules.py:5-27 of the reference (same ctor, same submodule tree: nonlinear.{i}, linear.{i}, gate.{i},
+    bn1, bn2, dropout1).  bn1 + dropout1 and bn2 are one launch each, every layer is three dense launches + one mix.
+    Only f = relu is provided (the only value the reference passes)."""
+
+    def __init__(self, size, num_layers, f=None):
+        super().__init__()
+        self.num_layers = num_layers
+        self.nonlinear = nn.ModuleList([nn.Linear(size, size) for _ in range(num_layers)])
+        self.linear = nn.ModuleList([nn.Linear(size, size) for _ in range(num_layers)])
+        self.gate = nn.ModuleList([nn.Linear(size, size) for _ in range(num_layers)])
+        self.f = f
+        self.bn1 = nn.BatchNorm1d(size)
+        self.bn2 = nn.BatchNorm1d(size)
+        self.dropout1 = nn.Dropout(0.7)
+
+    def forward(self, x, seed=None):
+        from .. import ops
+        p, seed = _drop_args(self.training, self.dropout1.p, seed)
+        x = ops.batchnorm(x, self.bn1, drop_p=p, seed=seed, site=0)
+        for layer in range(self.num_layers):
+            zg = ops.dense(x, self.gate[layer].weight, self.gate[layer].bias)
+            zn = ops.dense(x, self.nonlinear[layer].weight, self.nonlinear[layer].bias)
+            zl = ops.dense(x, self.linear[layer].weight, self.linear[layer].bias)
+            x = ops.highway_mix(zg, zn, zl)
+        return ops.batchnorm(x, self.bn2)
+
+
+class ResidualBlock(nn.Module):
+    """models/model_modules.py:29-49: fc1-bn1-relu-fc2-bn2, += residual, relu (bn2 + add + relu is one launch)."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.fc1 = nn.Linear(size, size)
+        self.bn1 = nn.BatchNorm1d(size)
+        self.relu = nn.ReLU(inplace=True)
+        self.fc2 = nn.Linear(size, size)
+        self.bn2 = nn.BatchNorm1d(size)
+
+    def forward(self, x):
+        from .. import ops
+        out = ops.batchnorm(ops.dense(x, self.fc1.weight, self.fc1.bias), self.bn1, act="relu")
+        return ops.batchnorm(ops.dense(out, self.fc2.weight, self.fc2.bias), self.bn2, res=x, act="relu")
+
+
+class Residual(nn.Module):
+    """models/model_modules.py:51-58."""
+
+    def __init__(self, size, n_layer):
+        super().__init__()
+        self.n_layer = n_layer
+        self.blocks = nn.ModuleList([ResidualBlock(size) for _ in range(n_layer)])
+
+    def forward(self, x):
+        for i in range(self.n_layer):
+            x = self.blocks[i](x)
+        return x
+
+
+def fcnn_block(seq, x, seed, site):
+    """Sequential(Linear, BatchNorm1d, ReLU, Dropout(p)[, Linear]) of the stage-2 models on the GPU:
+    dense, then BN + ReLU + dropout in one launch, then the optional last dense."""
+    from .. import ops
+    lin, bn, drop = seq[0], seq[1], seq[3]
+    p = drop.p if seq.training else 0.0
+    h = ops.batchnorm(ops.dense(x, lin.weight, lin.bias), bn, act="relu", drop_p=p, seed=seed, site=site)
+    if len(seq) > 4:
+        h = ops.dense(h, seq[4].weight, seq[4].bias)
+    return h
+
+
 class XlinearFusion(nn.Module):
     """Gated Kronecker ("tensor") fusion; drop-in for models/model_modules.py:128-178 of the reference
     (same ctor signature and submodule tree: reduce.{i}.{0,1,2}.0, encoder1.0, encoder2.0).
@@ -113,7 +191,11 @@ class XlinearFusion(nn.Module):
             seed = ops.next_dropout_seed()
         seed = seed or 0
         p = self.dropout_rate if tr else 0.0
-        if self.skip:          # the configuration the heads use: the whole block as one autograd node
+        B = v_list[0].shape[0]
+        sdim = self.reduce[0][0][0].weight.shape[0]
+        # the configuration the heads use (skip, B = 1): the whole block as one autograd node; its single-workgroup
+        # gating kernel holds m * B * sdim values in LDS, so larger batches (stage 2: B = 32) take the composable ops
+        if self.skip and len(v_list) * B * sdim <= 384:
             weights = []
             for i in range(len(v_list)):
                 for lin in (self.reduce[i][0][0], self.reduce[i][1][0], self.reduce[i][2][0]):

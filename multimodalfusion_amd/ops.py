@@ -476,3 +476,139 @@ class XFusionFn(torch.autograd.Function):
 def xfusion(v_list, weights, p=0.0, seed=0):
     """weights: [Wh_0, bh_0, Wz_0, bz_0, Wo_0, bo_0, ..., We1, be1, We2, be2]."""
     return XFusionFn.apply(len(v_list), p, seed, *v_list, *weights)
+
+
+# ---- stage-2 building blocks (SURVEY.md 8f N3; include/mmf_amil.h "Stage-2 building blocks") -------------------------
+class BatchNormFn(torch.autograd.Function):
+    """y = dropout(act(BatchNorm1d(x) [+ res])) in one launch; running statistics are updated in place (training)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, eps, momentum, act, drop_p, seed, site):
+        x = _f32c(x)
+        res = _f32c(res) if res is not None else None
+        B, F = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((F,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        check(lib().mmf_batchnorm_forward(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                          B, F, 1 if training else 0, float(eps), float(momentum), ACT[act],
+                                          float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(y), ptr(mean), ptr(invstd),
+                                          stream_ptr()), "mmf_batchnorm_forward")
+        ctx.cfg = (bool(training), act, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), res is not None)
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.mark_non_differentiable(running_mean, running_var) if running_mean is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        training, act, drop_p, seed, site, has_res = ctx.cfg
+        gy = _f32c(gy)
+        B, F = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty_like(mean)
+        dbeta = torch.empty_like(mean)
+        check(lib().mmf_batchnorm_backward(ptr(gy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), B, F,
+                                           1 if training else 0, ACT[act], drop_p, seed, site,
+                                           ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr()),
+              "mmf_batchnorm_backward")
+        return dx, dres, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), \
+            None, None, None, None, None, None, None, None, None
+
+
+def batchnorm(x, bn, res=None, act="none", drop_p=0.0, seed=0, site=0):
+    """Apply an nn.BatchNorm1d module's parameters / buffers on the GPU (train or eval as bn.training says)."""
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.0 if bn.momentum is None else bn.momentum
+    return BatchNormFn.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.eps, mom, act,
+                             drop_p, seed, site)
+
+
+class HighwayMixFn(torch.autograd.Function):
+    """models/model_modules.py:21-25: sigmoid(zg) * relu(zn) + (1 - sigmoid(zg)) * zl."""
+
+    @staticmethod
+    def forward(ctx, zg, zn, zl):
+        zg, zn, zl = _f32c(zg), _f32c(zn), _f32c(zl)
+        y = torch.empty_like(zg)
+        check(lib().mmf_highway_mix_forward(ptr(zg), ptr(zn), ptr(zl), zg.numel(), ptr(y), stream_ptr()),
+              "mmf_highway_mix_forward")
+        ctx.save_for_backward(zg, zn, zl)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        zg, zn, zl = ctx.saved_tensors
+        gy = _f32c(gy)
+        dzg, dzn, dzl = torch.empty_like(zg), torch.empty_like(zg), torch.empty_like(zg)
+        check(lib().mmf_highway_mix_backward(ptr(gy), ptr(zg), ptr(zn), ptr(zl), zg.numel(), ptr(dzg), ptr(dzn), ptr(dzl),
+                                             stream_ptr()), "mmf_highway_mix_backward")
+        return dzg, dzn, dzl
+
+
+def highway_mix(zg, zn, zl):
+    return HighwayMixFn.apply(zg, zn, zl)
+
+
+class RankLossFn(torch.autograd.Function):
+    """utils/loss_utils.py:58-101; loss and d(risks) in one launch."""
+
+    @staticmethod
+    def forward(ctx, risks, times, c, phi, reduction):
+        shape = risks.shape
+        r = _f32c(risks.reshape(-1))
+        B = r.numel()
+        if B == 1:
+            raise NotImplementedError("Batch size must be at least 2")          # as the reference (loss_utils.py:60-61)
+        t = torch.as_tensor(times).reshape(B).to(device=r.device, dtype=torch.float64).contiguous()
+        cc = c.reshape(B).to(device=r.device, dtype=torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=r.device)
+        dr = torch.empty_like(r)
+        check(lib().mmf_ranking_loss(ptr(r), ptr(t), ptr(cc), B, {"sigmoid": 0, "relu": 1}[phi],
+                                     {"mean": 0, "sum": 1}[reduction], ptr(loss), ptr(dr), stream_ptr()), "mmf_ranking_loss")
+        ctx.save_for_backward(dr)
+        ctx.shape = shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dr,) = ctx.saved_tensors
+        return (dr * g).reshape(ctx.shape), None, None, None, None
+
+
+def ranking_loss(risks, times, c, phi="sigmoid", reduction="mean"):
+    return RankLossFn.apply(risks, times, c, phi, reduction)
+
+
+class HazardFn(torch.autograd.Function):
+    """logits -> (risk, hazards, S, Y_hat): models/nll_models_pretrained.py:58-62."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = _f32c(logits)
+        B, K = logits.shape
+        hz, S = torch.empty_like(logits), torch.empty_like(logits)
+        risk = torch.empty((B,), dtype=torch.float32, device=logits.device)
+        Y_hat = torch.empty((B, 1), dtype=torch.int64, device=logits.device)
+        check(lib().mmf_hazards_forward(ptr(logits), B, K, ptr(hz), ptr(S), ptr(Y_hat), ptr(risk), stream_ptr()),
+              "mmf_hazards_forward")
+        ctx.save_for_backward(hz)
+        ctx.mark_non_differentiable(Y_hat)
+        return risk, hz, S, Y_hat
+
+    @staticmethod
+    def backward(ctx, g_risk, g_hz, g_S, _gY):
+        (hz,) = ctx.saved_tensors
+        B, K = hz.shape
+        f = lambda t: _f32c(t) if t is not None else None
+        dl = torch.empty_like(hz)
+        check(lib().mmf_hazards_backward(ptr(f(g_hz)), ptr(f(g_S)), ptr(f(g_risk)), ptr(hz), B, K, ptr(dl), stream_ptr()),
+              "mmf_hazards_backward")
+        return dl
+
+
+def hazards_from_logits(logits):
+    return HazardFn.apply(logits)

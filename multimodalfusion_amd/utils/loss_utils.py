@@ -29,3 +29,35 @@ class CoxSurvLoss(object):
         if not torch.is_tensor(times):
             times = torch.as_tensor(np.asarray(times), dtype=torch.float64)
         return ops.cox_surv(risks, times, c)
+
+
+def ranking_loss(risks, times, c, phi, reduction):
+    """utils/loss_utils.py:58-101 (pairwise loop over the batch) as one HIP launch."""
+    return ops.ranking_loss(risks, times, c, phi=phi, reduction=reduction)
+
+
+class RankingSurvLoss(object):
+    """utils/loss_utils.py:141-149."""
+
+    def __init__(self, phi="sigmoid", reduction="mean"):
+        super().__init__()
+        self.phi = phi
+        self.reduction = reduction
+
+    def __call__(self, risks, times, c):
+        return ranking_loss(risks, times, c, self.phi, self.reduction)
+
+
+class RankingNLLSurvLoss(object):
+    """utils/loss_utils.py:151-164: ranking over the BIN LABELS (`ranking_loss(risks, Y, c, ...)`, :160) + nll_ratio * nll."""
+
+    def __init__(self, phi="sigmoid", reduction="mean", alpha=0.15, nll_ratio=0.5):
+        self.alpha = alpha
+        self.phi = phi
+        self.reduction = reduction
+        self.nll_ratio = nll_ratio
+
+    def __call__(self, hazards, risks, S, Y, c, alpha=None):
+        ranking_ls = ranking_loss(risks, Y, c, self.phi, self.reduction)
+        nll_ls = nll_loss(hazards, S, Y, c, alpha=self.alpha if alpha is None else alpha)
+        return ranking_ls + nll_ls * self.nll_ratio
