@@ -133,9 +133,6 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_dma_kernel(LinearBfParams p
     const int col = col0 + epilogue_col<T>(nb);
     bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
   }
-#ifdef MMF_DIAG_NOEPI
-  if (p.drop_p == 12345.f)
-#endif
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
     const int col = col0 + c;
     if (col >= p.N) return;
@@ -151,9 +148,6 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_dma_kernel(LinearBfParams p
         y[e] = fmaxf(y[e], 0.f);
         if (p.drop_p > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
-      #ifdef MMF_DIAG_NOSTORE
-      if (p.drop_p == 12345.f)
-#endif
       *reinterpret_cast<uint2*>(p.y + (size_t)row * p.N + col) = pack4(y[0], y[1], y[2], y[3]);
     }
   });

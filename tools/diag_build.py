@@ -17,9 +17,7 @@ sys.path.insert(0, ROOT)
 from multimodalfusion_amd import build as B   # noqa: E402
 
 VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
-            "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
-            "nostore": ["-DMMF_DIAG_NOSTORE"], "noepi": ["-DMMF_DIAG_NOEPI"],
-            "noepi_nomfma": ["-DMMF_DIAG_NOEPI", "-DMMF_DIAG_NOMFMA"], "noepi_noload": ["-DMMF_DIAG_NOEPI", "-DMMF_DIAG_NOLOAD"]}
+            "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"]}
 
 
 def main():
