@@ -36,7 +36,7 @@ __device__ inline unsigned long long real_now() {      // constant 100 MHz count
 #define BST_MARK(k, slot)
 #define BST_COUNT(k)
 #endif
-enum { BST_LIN = 0, BST_GATE = 1, BST_DH = 2, BST_TN = 3 };
+enum { BST_LIN = 0, BST_GATE = 1, BST_DH = 2, BST_TN = 3 };   // the fused forward uses BST_LIN: {projection loop, its epilogue, gate phase, pooling}
 
 void debug_stamps_bf16(unsigned long long* out32) {
 #ifdef MMF_STAMPS
@@ -170,7 +170,7 @@ int launch_linear_bf16(LinearBfParams p, hipStream_t st) {
 }
 
 // =============================================================================================
-// K-gate : a, b saved as bf16; per-row partial scores from the unrounded epilogue values
+// K-gate : a, b saved as bf16; per-row partial scores from those same (rounded) values
 // =============================================================================================
 // B-operand rows alternate 32-row blocks (a, b) of the same 32 attention dims (the fp32 kernel's layout): a wave's
 // nb = 2t, 2t+1 accumulators are the tanh and the sigmoid pre-activation of the same (instance, d).
@@ -266,11 +266,15 @@ __global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
           bv[0] = fast_sigmoid(vb[q].x + bb4.x); bv[1] = fast_sigmoid(vb[q].y + bb4.y);
           bv[2] = fast_sigmoid(vb[q].z + bb4.z); bv[3] = fast_sigmoid(vb[q].w + bb4.w);
         }
+        // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
+        const uint2 pa = pack4(av[0], av[1], av[2], av[3]), pb = pack4(bv[0], bv[1], bv[2], bv[3]);
+        unpack2(pa.x, av[0], av[1]); unpack2(pa.y, av[2], av[3]);
+        if constexpr (GATED) { unpack2(pb.x, bv[0], bv[1]); unpack2(pb.y, bv[2], bv[3]); }
         if (row < p.N && dok) {
           const size_t o = (size_t)row * p.D + d;
           if (p.a) {     // null in forward-only (inference) calls
-            *reinterpret_cast<uint2*>(p.a + o) = pack4(av[0], av[1], av[2], av[3]);
-            if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pack4(bv[0], bv[1], bv[2], bv[3]);
+            *reinterpret_cast<uint2*>(p.a + o) = pa;
+            if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pb;
           }
           const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
           const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
@@ -395,6 +399,255 @@ int launch_pool_bf16(PoolBfParams pb, hipStream_t st) {
   { ProfScope ps("pool_partial_bf16_kernel", st); hipLaunchKernelGGL(pool_partial_bf16_kernel, dim3(p.n_groups), dim3(256), 0, st, pb); }
   if (hipGetLastError() != hipSuccess) return MMF_ERR_LAUNCH;
   return launch_pool_merge(p, st);
+}
+
+// =============================================================================================
+// K-fwd (fused): instance projection + gated attention scoring + pooling partials in ONE kernel (H = D = 256, gated).
+//   "LDS-tiled attention": the [128 x 256] bf16 h tile a workgroup has just produced stays in LDS as the A operand
+//   of the gate GEMM and as the pooled operand, so h is written once (for the backward) and never read back in the
+//   forward; the tile's scores are complete inside the workgroup, so the online-softmax partial (max, sum e,
+//   sum e.h) is taken in place.  Replaces K-lin + K-gate + K-pool-partial: -2 launches, -2 reads of h.
+//   Phase 2 keeps the WEIGHTS stationary in registers: wave w owns gate columns (a, b) of attention dims
+//   32 w .. 32 w + 31 for all 128 rows, i.e. 64 rows of [Wa ; Wb] x K = 256 as 32 MFMA B-fragments (128 VGPRs),
+//   fetched once per workgroup straight from L2 while the phase-1 epilogue runs.  No staging, no barrier and no
+//   memory wait inside the gate GEMM (a two-stage DMA version of this phase spent 2/3 of its time waiting for the
+//   next 32 KB weight chunk: 1024 MFMA cycles per chunk cannot cover an L2 round trip).
+// LDS map (bytes):  phase 1: three 48 KB stages from 0, its epilogue's fp32 transpose scratch at 86016
+//                   [0, 20480) per-wave bf16 transpose scratch of phase 2
+//                   [20480, 86016) h tile: 4 k-chunks x [128 rows][128 B], XOR-swizzled like a staged chunk
+//                   [151552, ...) score partials [8][128], e[128], reduction scratch
+// =============================================================================================
+constexpr int FF_SCR2 = 0, FF_HIMG = 20480, FF_SCR1 = 86016, FF_MISC = 151552;
+constexpr int FF_LDS_BYTES = FF_MISC + (8 * 128 + 128 + 4 * 256 + 16) * 4;
+
+__global__ __launch_bounds__(512) void amil_fwd_fused_bf16_kernel(FusedFwdParams p) {
+  using T = TileS128;
+  extern __shared__ __align__(16) char ldsf[];
+  char* lds = ldsf;
+  const int mt = blockIdx.x;
+  const int row0 = mt * T::BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const uint32_t sdev = p.seed_dev ? *p.seed_dev : 0u;
+  float* sred = reinterpret_cast<float*>(lds + FF_MISC);        // [8 waves][128 rows]
+  float* e_l = sred + 8 * 128;                                   // [128]
+  float* vred = e_l + 128;                                       // [4][256]
+  float* red = vred + 4 * 256;                                   // [16]
+  BST_BEGIN();
+
+  // ---------------- phase 1: u = x.W1^T (K = L), three-stage LDS-DMA pipeline -------------------------------
+  f32x16 acc[T::MB][T::NB];
+  {
+    DmaK<T::BM, T::NT> la;
+    la.init(p.x, p.L, row0, (int)p.N);
+    DmaK<T::BN, T::NT> lb;
+    lb.init(p.w1, p.L, 0, 256);
+    gemm_mainloop_dma<T>(la, lb, p.L / 64, lds, acc);
+  }
+  BST_MARK(BST_LIN, 0);
+  // the wave's stationary gate weights: B-fragments of rows 32 w + r of Wa (nb 0) and Wb (nb 1), all of K = 256;
+  // issued now, consumed after the epilogue below
+  float4 wfr[2][16];
+  {
+    const unsigned wbytes = 256u * 256u * 2u;
+    const rsrc_t ra = make_rsrc(p.Wa, wbytes), rb = make_rsrc(p.Wb, wbytes);
+    const unsigned voff = (unsigned)(32 * wave + r) * 512u + (unsigned)hh * 16u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                       // j = 4 kc + q: k bytes = 128 kc + 32 q (+ 16 hh)
+      wfr[0][j] = bld4(ra, voff, (unsigned)((j >> 2) * 128 + (j & 3) * 32));
+      wfr[1][j] = bld4(rb, voff, (unsigned)((j >> 2) * 128 + (j & 3) * 32));
+    }
+  }
+  // epilogue: h = bf16(drop(relu(u + b1))) -> HBM (for backward) and -> the LDS h tile (A operand of phase 2)
+  {
+    const uint32_t thr = drop_threshold(p.p_h);
+    const float scale = p.p_h > 0.f ? 1.0f / (1.0f - p.p_h) : 1.0f;
+    const uint32_t dkey = p.key_h + sdev;
+    float4 bias4[T::NB];
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) bias4[nb] = ld4(p.b1 + epilogue_col<T>(nb));
+    epilogue_rows<T>(acc, reinterpret_cast<float*>(lds + FF_SCR1), [&](int mb, int nb, int rr, int c, const float4 (&v)[4]) {
+      const float4 b4 = bias4[nb];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int R = rr + 8 * t, row = row0 + R;
+        float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
+        const uint32_t idx = (uint32_t)row * 256u + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = fmaxf(y[e], 0.f);
+          if (p.p_h > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
+        }
+        const uint2 pk = pack4(y[0], y[1], y[2], y[3]);
+        if (p.h && row < p.N) *reinterpret_cast<uint2*>(p.h + (size_t)row * 256 + c) = pk;
+        const int cc = c & 63;
+        *reinterpret_cast<uint2*>(lds + FF_HIMG + (c >> 6) * 16384 + R * 128 + 16 * ((cc >> 3) ^ ((R >> 1) & 7)) + (cc & 7) * 2) = pk;
+      }
+    });
+  }
+  // per-wave constants of the phase-2 epilogue
+  const int dj = 32 * wave + r;                            // this lane's dim in the accumulator layout
+  const float bia = p.ba[dj], bib = p.bb[dj];
+  const int rowl = lane >> 1, half = lane & 1;             // after the transpose: 16 dims of one row per lane
+  const int dq = 32 * wave + half * 16;
+  float wc[16];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const float4 t = ld4(p.Wc + dq + 4 * q4);
+    wc[4 * q4] = t.x; wc[4 * q4 + 1] = t.y; wc[4 * q4 + 2] = t.z; wc[4 * q4 + 3] = t.w;
+  }
+  __syncthreads();                                         // h tile complete
+  BST_MARK(BST_LIN, 1);
+
+  // ---------------- phase 2: [128 x 256] h tile . [64 weight rows of this wave]^T, weights in registers ----------
+  const uint32_t thr_a = drop_threshold(p.p_att);
+  const bool drop = p.p_att > 0.f;
+  const float dscale = drop ? 1.0f / (1.0f - p.p_att) : 1.0f;
+  const uint32_t key_a = p.key_a + sdev, key_b = p.key_b + sdev;
+  char* scr = lds + FF_SCR2 + wave * 2560;                 // [32 rows][80 B] bf16 transpose scratch of this wave
+  const int sw = (r >> 1) & 7;
+#pragma unroll 1
+  for (int hf = 0; hf < 2; ++hf) {                         // two 64-row halves: 2 x 2 accumulator blocks at a time
+    f32x16 ag[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ag[mb][nb][i] = 0.f;
+    const char* a0 = lds + FF_HIMG + (hf * 64 + r) * 128;
+    float4 fa[2][2];
+    fa[0][0] = *reinterpret_cast<const float4*>(a0 + 16 * (hh ^ sw));
+    fa[0][1] = *reinterpret_cast<const float4*>(a0 + 32 * 128 + 16 * (hh ^ sw));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                         // j = 4 kc + q
+      if (j + 1 < 16) {
+        const int kc = (j + 1) >> 2, q = (j + 1) & 3;
+        const int o = kc * 16384 + 16 * ((2 * q + hh) ^ sw);
+        fa[(j + 1) & 1][0] = *reinterpret_cast<const float4*>(a0 + o);
+        fa[(j + 1) & 1][1] = *reinterpret_cast<const float4*>(a0 + 32 * 128 + o);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float av[4] = {fa[j & 1][mb].x, fa[j & 1][mb].y, fa[j & 1][mb].z, fa[j & 1][mb].w};
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const float bv[4] = {wfr[nb][j].x, wfr[nb][j].y, wfr[nb][j].z, wfr[nb][j].w};
+          ag[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_bf16(av), frag_bf16(bv), ag[mb][nb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- activations in the accumulator layout, bf16 transpose through LDS, stores of a / b, score partials ----
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int R = hf * 64 + mb * 32 + rowl, row = row0 + R;
+      float4 qa[2], qb[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        *reinterpret_cast<bf16_t*>(scr + rr * 80 + r * 2) = f2bf(fast_tanh(ag[mb][0][i] + bia));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      qa[0] = *reinterpret_cast<const float4*>(scr + rowl * 80 + half * 32);
+      qa[1] = *reinterpret_cast<const float4*>(scr + rowl * 80 + half * 32 + 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        *reinterpret_cast<bf16_t*>(scr + rr * 80 + r * 2) = f2bf(fast_sigmoid(ag[mb][1][i] + bib));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      qb[0] = *reinterpret_cast<const float4*>(scr + rowl * 80 + half * 32);
+      qb[1] = *reinterpret_cast<const float4*>(scr + rowl * 80 + half * 32 + 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (p.a && row < p.N) {
+        float4* oa = reinterpret_cast<float4*>(p.a + (size_t)row * 256 + dq);
+        float4* ob = reinterpret_cast<float4*>(p.b + (size_t)row * 256 + dq);
+        oa[0] = qa[0]; oa[1] = qa[1];
+        ob[0] = qb[0]; ob[1] = qb[1];
+      }
+      float av[16], bv[16];
+      unpack8(qa[0], *reinterpret_cast<float(*)[8]>(av));
+      unpack8(qa[1], *reinterpret_cast<float(*)[8]>(av + 8));
+      unpack8(qb[0], *reinterpret_cast<float(*)[8]>(bv));
+      unpack8(qb[1], *reinterpret_cast<float(*)[8]>(bv + 8));
+      const uint32_t idx = (uint32_t)row * 256u + (uint32_t)dq;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float ad = av[e], bd = bv[e];
+        if (drop) {
+          ad = keep(key_a, idx + e, thr_a) ? ad * dscale : 0.f;
+          bd = keep(key_b, idx + e, thr_a) ? bd * dscale : 0.f;
+        }
+        s += ad * bd * wc[e];
+      }
+      s += __shfl_xor(s, 1, 64);
+      if (half == 0) sred[wave * 128 + R] = s;
+    }
+  }
+  __syncthreads();
+  BST_MARK(BST_LIN, 2);
+
+  // ---------------- scores of the tile, online-softmax partial ------------------------------------------------
+  const float bc = p.bc[0];
+  float sv = -INFINITY;
+  if (tid < 128) {
+    const int row = row0 + tid;
+    float s = bc;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += sred[w * 128 + tid];
+    if (row < p.N) { p.A_raw[row] = s; sv = s; }
+  }
+  float m = wave_max(sv);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);                               // the rows live in threads 0..127 = waves 0, 1
+  const float ev = sv > -INFINITY ? __expf(sv - m) : 0.f;
+  if (tid < 128) e_l[tid] = ev;
+  const float lsum = wave_sum(ev);
+  if (lane == 0) red[8 + wave] = lsum;
+  __syncthreads();
+  {
+    const int cp = tid & 127, rg = tid >> 7, c = 2 * cp;   // columns c, c+1; rows rg*32 .. +31
+    const int cc = c & 63;
+    const char* hb = lds + FF_HIMG + (c >> 6) * 16384 + (cc & 7) * 2;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+      const int R = rg * 32 + i;
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(hb + R * 128 + 16 * ((cc >> 3) ^ ((R >> 1) & 7)));
+      float h0, h1;
+      unpack2(w, h0, h1);
+      const float e = e_l[R];
+      v0 += e * h0; v1 += e * h1;
+    }
+    vred[rg * 256 + c] = v0;
+    vred[rg * 256 + c + 1] = v1;
+  }
+  __syncthreads();
+  float* out = p.partials + (size_t)mt * (2 + 256);
+  if (tid < 256) out[2 + tid] = vred[tid] + vred[256 + tid] + vred[512 + tid] + vred[768 + tid];
+  if (tid == 0) { out[0] = m; out[1] = red[8] + red[9]; }
+  BST_MARK(BST_LIN, 3);
+  BST_COUNT(BST_LIN);
+}
+
+int fused_fwd_tiles(int64_t N) { return (int)((N + 127) / 128); }
+bool fused_fwd_ok(int64_t N, int L, int H, int D) {     // callers also require gated && D == 256 (8 waves x 32 dims)
+  static const int env = getenv("MMF_BF16_FUSED") ? atoi(getenv("MMF_BF16_FUSED")) : 1;   // A/B switch
+  (void)D;
+  return env && H == 256 && L % 64 == 0 && fused_fwd_tiles(N) <= 4096;
+}
+
+int launch_fused_fwd_bf16(FusedFwdParams p, int gated, hipStream_t st) {
+  if (!gated || p.D != 256) return MMF_ERR_SHAPE;
+  p.mt_count = fused_fwd_tiles(p.N);
+  auto kern = amil_fwd_fused_bf16_kernel;
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), FF_LDS_BYTES)) return e;
+  ProfScope ps("amil_fwd_fused_bf16_kernel", st);
+  hipLaunchKernelGGL(kern, dim3(p.mt_count), dim3(512), FF_LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
 // =============================================================================================

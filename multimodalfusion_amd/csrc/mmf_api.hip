@@ -158,7 +158,10 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   w.wabT = take16((size_t)H * w.mstk);
   w.h = take16((size_t)N * H);
   w.s_part = take32((size_t)w.parts * N);
-  w.partials = take32((size_t)w.groups * (2 + H));
+  {
+    const int tiles = fused_fwd_tiles(N);          // the fused forward writes one pooling partial per 128-row tile
+    w.partials = take32((size_t)(w.groups > tiles ? w.groups : tiles) * (2 + H));
+  }
   w.stats = take32(4);
   if (infer) {
     w.bytes = off;
@@ -358,6 +361,24 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
   }
   if (int e = launch_cvt_bf16(cp, st)) return e;
+
+  if (d->gated && d->D == 256 && fused_fwd_ok(d->N, d->L, d->H, d->D)) {   // `small` gated stack: one kernel for projection + scoring + pooling partials
+    FusedFwdParams fp{};
+    fp.x = x; fp.w1 = w.w1; fp.b1 = d->b1;
+    fp.Wa = w.wab; fp.Wb = d->gated ? w.wab + (size_t)d->D * d->H : nullptr;
+    fp.ba = d->ba; fp.bb = d->bb; fp.Wc = d->Wc; fp.bc = d->bc;
+    fp.h = infer ? nullptr : w.h; fp.a = w.a; fp.b = w.b;       // a / b are null when carved for inference
+    fp.A_raw = A_raw; fp.partials = w.partials;
+    fp.N = d->N; fp.L = d->L; fp.D = d->D;
+    fp.p_h = d->p_h; fp.p_att = d->p_att;
+    fp.key_h = drop_key(d->seed, 0); fp.key_a = drop_key(d->seed, 1); fp.key_b = drop_key(d->seed, 2);
+    fp.seed_dev = g_seed_dev;
+    if (int e = launch_fused_fwd_bf16(fp, d->gated, st)) return e;
+    PoolParams pm{};
+    pm.N = d->N; pm.H = d->H; pm.partials = w.partials; pm.M = M; pm.stats = w.stats;
+    pm.n_groups = fused_fwd_tiles(d->N);
+    return launch_pool_merge(pm, st);
+  }
 
   LinearBfParams lp{};
   lp.x = x; lp.w = w.w1; lp.bias = d->b1; lp.y = w.h;

@@ -4,8 +4,8 @@
 // (h, a, b, du, and the on-the-fly dP operand).  What stays fp32: parameters (masters), biases, Wc, the MFMA
 // accumulators, every epilogue (bias, ReLU, tanh, sigmoid, dropout scale, scores, softmax, pooling), the
 // gradients handed back, and the split-K slabs.  Rounding is round-to-nearest-even at exactly these points:
-//   x (given), bf16(W1), bf16(Wa), bf16(Wb);  h = bf16(drop(relu(u)));  a = bf16(tanh), b = bf16(sigmoid) AS SAVED
-//   (the scores use the unrounded a, b of the epilogue registers);  dP = bf16(gate_dp(a, b, ...));  du = bf16(...).
+//   x (given), bf16(W1), bf16(Wa), bf16(Wb);  h = bf16(drop(relu(u)));  a = bf16(tanh), b = bf16(sigmoid) (saved, and
+//   what the scores are computed from);  dP = bf16(gate_dp(a, b, ...));  du = bf16(...).
 // The oracle restates the same points (oracle/torch_port.py: bf16 mode).
 #pragma once
 #include "mmf_kernels.h"
@@ -102,6 +102,18 @@ int launch_linear_bf16(LinearBfParams p, hipStream_t st);
 int gate_parts_bf16(int D, int gated);
 int launch_gate_bf16(GateBfParams p, hipStream_t st);
 int launch_pool_bf16(PoolBfParams p, hipStream_t st);
+struct FusedFwdParams {     // fused forward (H = 256): instance projection + gate scoring + pooling partials
+  const bf16_t* x; const bf16_t* w1; const float* b1;
+  const bf16_t *Wa, *Wb; const float *ba, *bb, *Wc, *bc;
+  bf16_t *h, *a, *b;            // saved for backward; all three null in forward-only calls
+  float* A_raw; float* partials;   // partials: [fused_fwd_tiles(N)][2 + 256] = (max, sum e, sum e.h) per 128-row tile
+  int64_t N; int L, D;
+  float p_h, p_att; uint32_t key_h, key_a, key_b; const uint32_t* seed_dev;
+  int mt_count;
+};
+int fused_fwd_tiles(int64_t N);
+bool fused_fwd_ok(int64_t N, int L, int H, int D);
+int launch_fused_fwd_bf16(FusedFwdParams p, int gated, hipStream_t st);
 int dh_bf16_row_tiles(int64_t N);              // capacity of dbc_part (upper bound over tile choices)
 int dh_bf16_tiles_used(int64_t N, int ntn);     // dbc partials launch_dh_bf16 writes for this shape
 int launch_dh_bf16(DhBfParams p, hipStream_t st);

@@ -58,14 +58,14 @@ def amil_bf16(sd, prefix, x, gated, dropout, masks=None, rnd=rb):
     W1q, Waq = r(W1), r(Wa)
     Wbq = r(Wb) if gated else None
     h = r(torch.relu(x @ W1q.T + b1) * m_h)                  # saved bf16
-    a = torch.tanh(h @ Waq.T + ba)
-    b = torch.sigmoid(h @ Wbq.T + bb) if gated else None
-    ab = (a * m_a) * (b * m_b) if gated else a * m_a         # scores from the UNROUNDED a, b
+    a = r(torch.tanh(h @ Waq.T + ba))                        # saved bf16; the scores use the same rounded values
+    b = r(torch.sigmoid(h @ Wbq.T + bb)) if gated else None
+    ab = (a * m_a) * (b * m_b) if gated else a * m_a
     s = ab @ Wc.T + bc                                       # [N x 1]
     A_raw = s.T
     p = torch.softmax(A_raw, dim=1)                          # [1 x N]
     M = p @ h
-    saved = dict(x=x, h=h, a=r(a), b=r(b) if gated else None, p=p, M=M, Wc=Wc, Waq=Waq, Wbq=Wbq,
+    saved = dict(x=x, h=h, a=a, b=b, p=p, M=M, Wc=Wc, Waq=Waq, Wbq=Wbq,
                  m_h=m_h, m_a=m_a, m_b=m_b, gated=gated, rnd=r)
     return M, A_raw, saved
 

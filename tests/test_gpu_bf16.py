@@ -3,7 +3,8 @@
 Two references:
   * oracle/bf16_port.py with the kernels' rounding points (pinned on CPU by tests/test_oracle_bf16.py).  HIP and oracle
     then differ only by fp32-vs-fp64 accumulation, which can flip a bf16 rounding of a saved activation in a few
-    elements (1 bf16 ulp = 2^-8 relative); tolerances: scores/hazards 2e-3 abs, loss 1e-3, gradients 1 % in norm;
+    elements (1 bf16 ulp = 2^-8 relative: a flipped h or a / b element moves one score by up to ~2.5e-3, measured);
+    tolerances: scores 5e-3 abs with the 99th percentile below 2e-4, hazards 2e-3, loss 1e-3, gradients 1 % in norm;
   * the fp32/fp64 reference fixtures: bf16 quantisation only (scores 3e-2, hazards 1e-2, gradients 15 % in norm).
 """
 import numpy as np
@@ -47,6 +48,8 @@ def compare_bf16(res, ref, tag, a_tol, h_tol, l_tol, g_rel):
     assert abs(res["loss"] - float(ref["loss"])) <= l_tol, (tag, res["loss"], float(ref["loss"]))
     np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=h_tol, err_msg=tag)
     np.testing.assert_allclose(res["A_raw"], ref["A_raw"], rtol=0, atol=a_tol, err_msg=tag)
+    if a_tol < 1e-2 and res["A_raw"].size >= 100:        # vs the bf16 oracle: outliers are rare rounding flips
+        assert float(np.quantile(np.abs(res["A_raw"] - ref["A_raw"]), 0.99)) <= 2e-4, tag
     if res.get("M") is not None:
         np.testing.assert_allclose(res["M"], ref["M"], rtol=0, atol=a_tol, err_msg=tag)
     for k, g in ref["grads"].items():
@@ -77,7 +80,7 @@ def test_bf16_path_golden_cases(golden, monkeypatch):
             continue
         xq = _xq(m)
         res = run_path_hip_bf16(m, monkeypatch, xq)
-        compare_bf16(res, _oracle(m, xq), name + "/bf16-oracle", a_tol=2e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
+        compare_bf16(res, _oracle(m, xq), name + "/bf16-oracle", a_tol=5e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
         compare_bf16(res, cases.run_path(m), name + "/fp64-reference", a_tol=3e-2, h_tol=1e-2, l_tol=3e-2, g_rel=0.15)
         n += 1
     assert n >= 8
@@ -90,7 +93,7 @@ def test_bf16_path_mid_sizes(monkeypatch, N):
              mask_seed=4242, y=1, c=0, alpha=0.0)
     xq = _xq(m)
     res = run_path_hip_bf16(m, monkeypatch, xq)
-    compare_bf16(res, _oracle(m, xq), f"N={N}", a_tol=2e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
+    compare_bf16(res, _oracle(m, xq), f"N={N}", a_tol=5e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
 
 
 def test_bf16_100k_properties():

@@ -23,5 +23,7 @@ for k, name in enumerate(["linear", "gate", "dh", "tn"]):
     w = max(v[7], 1)
     tot = v[0] + v[1] + v[2]
     mhz = tot / max(v[6], 1) * 100.0            # shader cycles per 100 MHz tick
-    print(f"{name:7s} waves/launch {v[7] // R:6d}  per wave shader cycles: prologue {v[0] / w:9.0f}  mainloop {v[1] / w:9.0f}  "
-          f"epilogue {v[2] / w:9.0f}   wave life {v[6] / w / 100.0:7.1f} us  (clock {mhz:6.0f} MHz)")
+    tot = v[0] + v[1] + v[2] + v[3]
+    mhz = tot / max(v[6], 1) * 100.0
+    print(f"{name:7s} waves/launch {v[7] // R:6d}  per wave shader cycles: slot0 {v[0] / w:9.0f}  slot1 {v[1] / w:9.0f}  "
+          f"slot2 {v[2] / w:9.0f}  slot3 {v[3] / w:9.0f}   wave life {v[6] / w / 100.0:7.1f} us  (clock {mhz:6.0f} MHz)")
