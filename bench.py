@@ -330,6 +330,7 @@ def main():
         }
         # bf16 storage: every kernel is HBM-bound; minimal bytes each kernel must move per launch
         kbytes = {
+            "amil_fwd_fused_bf16_kernel": N * (1024 * 2 + 256 * 2 + 2 * 256 * 2 + 4),     # x read; h, a, b, A_raw written
             "linear_bf16_kernel": N * (1024 * 2 + 256 * 2),                    # x read, h written
             "gate_bf16_kernel": N * (256 * 2 + 2 * 256 * 2 + 2 * 4),           # h read; a, b, 2 score parts written
             "pool_partial_bf16_kernel": N * (256 * 2 + 3 * 4),                 # h read; score parts read, A_raw written
