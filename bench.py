@@ -115,6 +115,21 @@ def time_steps(step, steps, warmup, world):
     return dt
 
 
+def step_percentiles(step, steps):
+    """Per-step device time from HIP events on the compute stream (median and p10 / p90)."""
+    import torch
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    q = lambda f: ms[min(len(ms) - 1, int(f * len(ms)))]
+    return {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90)}
+
+
 def kernel_profile(step, steps):
     """Per-kernel average duration from HIP events recorded on the launch stream (library hook)."""
     import torch
@@ -252,10 +267,16 @@ def cpu_baseline(N, n_bags):
     for _ in range(n_bags):
         one()
     dt = time.perf_counter() - t0
-    return dict(value=n_bags / dt, unit="bags/s", cores=best_t, kind="port",
+    # single-thread figure (SURVEY 8d asks for both): one timed bag
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    one()
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(best_t)
+    return dict(value=n_bags / dt, unit="bags/s", cores=best_t, kind="port", value_1_thread=1.0 / dt1,
                 sample=f"{n_bags} bags of {N}x1024 fwd+nll_surv+bwd after warm-up, fp32, train mode "
                        f"(1 dropout mask), torch {torch.__version__} CPU, {best_t} intra-op threads "
-                       f"(fastest of 8/16/32/64 on a host showing {avail} cores)")
+                       f"(fastest of 8/16/32/64 on a host showing {avail} cores); value_1_thread: one bag on one thread")
 
 
 def main():
@@ -320,6 +341,7 @@ def main():
         # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ----
         # rank 0 only: this leg must NOT contain the collective (the other ranks are already at the final barrier)
         local_step = make_step(model, x, dev, flat, 1)
+        out["step_ms_device"] = step_percentiles(local_step, max(10, min(args.steps, 50)))
         prof = kernel_profile(local_step, max(5, min(args.steps, 20)))
         dom = max(prof.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0] if prof else None
         kflops = {

@@ -177,45 +177,58 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   LoadP_K<T::BM, T::NT> la;
   if constexpr (FUSED) {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
-    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
-    float dmm = 0.f;
-    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
-    dmm = wave_sum(dmm);
-    float4 dm_l[4];                              // dM of this lane's columns (H <= 1024)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dm_l[q] = (4 * lane + 256 * q) < p.H ? ld4(p.dM + 4 * lane + 256 * q) : zero4();
-    float dbc = 0.f;
+    // g_i = dM.h_i: every wave takes a contiguous share of the rows; lanes cover float4 pieces of h with 8
+    // independent loads in flight (the first version loaded 4 rows, reduced, repeated: latency-bound)
     constexpr int NW = T::NT / 64;
-    for (int r0 = wave * 4; r0 < T::BM; r0 += NW * 4) {     // 4 rows per step: 4 independent loads in flight
-      float g[4];
+    constexpr int RPW = (T::BM + NW - 1) / NW;       // rows per wave (the last wave may own fewer)
+    float* g_l = p_l + T::BM + 16;                   // [BM] behind ds, p and the reduction scratch
+    const int LPR = p.H / 4;                         // float4 pieces per row: 64, 128 or 256
+    const int PPL = LPR / 64;                        // pieces per lane and row: 1, 2 or 4
+    float4 dm_l[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = row0 + r0 + u;
+    for (int q = 0; q < 4; ++q) dm_l[q] = q < PPL ? ld4(p.dM + 4 * (lane + 64 * q)) : zero4();
+    const int wr0 = wave * RPW, wr1 = wr0 + RPW < T::BM ? wr0 + RPW : T::BM;
+    for (int rb = wr0; rb < wr1; rb += 8) {          // 8 rows at a time
+      float part[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = row0 + rb + u;
         const int rc = row < p.N ? row : (int)p.N - 1;
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (4 * lane + 256 * q < p.H) {
-            float4 hv = ld4(p.h + (size_t)rc * p.H + 4 * lane + 256 * q);
+          if (q < PPL) {
+            const float4 hv = ld4(p.h + (size_t)rc * p.H + 4 * (lane + 64 * q));
             acc += hv.x * dm_l[q].x + hv.y * dm_l[q].y + hv.z * dm_l[q].z + hv.w * dm_l[q].w;
           }
-        g[u] = acc;
+        part[u] = acc;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) g[u] = wave_sum(g[u]);
-      if (lane < 4 && r0 + lane < T::BM) {
-        const int row = row0 + r0 + lane;
-        const float gv = lane == 0 ? g[0] : (lane == 1 ? g[1] : (lane == 2 ? g[2] : g[3]));
-        float pi = 0.f, d = 0.f;
-        if (row < p.N) {
-          pi = __expf(p.A_raw[row] - smax) * inv;
-          d = pi * (gv - dmm) + (p.gA ? p.gA[row] : 0.f);
-          if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
-        }
-        ds_l[r0 + lane] = d;
-        p_l[r0 + lane] = pi;
-        dbc += d;
+      for (int u = 0; u < 8; ++u) part[u] = wave_sum(part[u]);
+      if (lane < 8 && rb + lane < wr1) {
+        float gv = part[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) gv = lane == u ? part[u] : gv;
+        g_l[rb + lane] = gv;
       }
+    }
+    float dmm = 0.f;
+    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
+    dmm = wave_sum(dmm);
+    __syncthreads();
+    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
+    float dbc = 0.f;
+    for (int rr = tid; rr < T::BM; rr += T::NT) {
+      const int row = row0 + rr;
+      float pi = 0.f, d = 0.f;
+      if (row < p.N) {
+        pi = __expf(p.A_raw[row] - smax) * inv;
+        d = pi * (g_l[rr] - dmm) + (p.gA ? p.gA[row] : 0.f);
+        if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+      }
+      ds_l[rr] = d;
+      p_l[rr] = pi;
+      dbc += d;
     }
     dbc = wave_sum(dbc);
     float* red = p_l + T::BM;
@@ -627,7 +640,7 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
   const int grid = grid_for_tiles(p.mt_count, p.nt_count);
   if (p.fused_prep)
-    return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid, (2 * T::BM + 16) * 4, st);
+    return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid, (3 * T::BM + 16) * 4, st);
   return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid, st);
 }
 
