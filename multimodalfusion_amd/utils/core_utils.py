@@ -185,3 +185,43 @@ def validate_survival(cur, epoch, model, loader, n_classes, mode, early_stopping
             print("Early stopping")
             return True
     return False
+
+
+def summary_survival(model, loader, n_classes, mode, t_bin=None, loss_fn=None):
+    """utils/core_utils.py:358-430: eval-mode pass over a loader -> (patient_results, c_index).
+    risk = the head's scalar output for Cox / ranking losses, -sum(S) for the discrete-hazard losses; subjects whose
+    required modality is the "missing" sentinel are skipped exactly as in the reference (:379-386).  Subject ids are
+    read from `loader.dataset.slides_radio_data['subject_id']` when the loader has one (the reference requires it),
+    else the running index is used.  One device -> host copy at the end instead of one per subject."""
+    from .loss_utils import RankingSurvLoss
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    model.eval()
+    ids = None
+    ds = getattr(loader, "dataset", None)
+    if ds is not None and hasattr(ds, "slides_radio_data"):
+        ids = list(ds.slides_radio_data["subject_id"])
+    all_ids, all_risk, all_c, all_t, all_y = [], [], [], [], []
+    count = 0
+    with torch.no_grad():
+        for (radio_features, path_features, genomic_features, label, event_time, c) in loader:
+            n = len(label)
+            sid = ids[count:count + n] if ids is not None else list(range(count, count + n))
+            count += n
+            if _skip(mode, radio_features, path_features, genomic_features):
+                continue
+            feats, label, c = _to_device(radio_features, path_features, genomic_features, label, c, device)
+            hazards, S, Y_hat, _ = model(**feats)
+            risk = hazards if isinstance(loss_fn, (CoxSurvLoss, RankingSurvLoss)) else -torch.sum(S, dim=1)
+            all_ids.extend(sid)
+            all_risk.append(risk.reshape(-1))
+            all_c.append(c.reshape(-1))
+            all_t.append(np.asarray(event_time).reshape(-1))
+            all_y.append(label.reshape(-1))
+    risks = torch.cat(all_risk).cpu().numpy()
+    cens = torch.cat(all_c).cpu().numpy()
+    labels = torch.cat(all_y).cpu().numpy()
+    times = np.concatenate(all_t)
+    patient_results = {"subject_id": np.asarray(all_ids), "risk": risks, "disc_label": labels, "survival": times,
+                       "censorship": cens}
+    c_index = concordance_index_censored((1 - cens).astype(bool), times, risks, tied_tol=1e-08)[0]
+    return patient_results, c_index

@@ -112,3 +112,29 @@ def test_trajectory_matches_reference(golden):
     for si, snap in enumerate(snaps, start=1):
         for k, v in snap.items():
             check_summary(g, f"f64/step{si}/{k}", v, rtol=2e-5, atol=2e-6)
+
+
+def test_summary_survival_matches_per_bag_forward(golden):
+    """utils/core_utils.py:358-430: per-subject risk = -sum(S) and the c-index over the loader; missing modality skipped."""
+    from multimodalfusion_amd.utils.core_utils import concordance_index_censored, summary_survival
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    g, meta, sd, model, loader = _setup(golden)
+    loader = list(loader)
+    times = [10.0, 3.0, 7.0, 1.0]
+    loader = [(b[0], b[1], b[2], b[3], np.array([times[i % 4]]), b[5]) for i, b in enumerate(loader)]
+    loader.insert(1, ({"T1": torch.zeros(1, 1)}, torch.zeros(1, 1), torch.zeros(1, 4), torch.tensor([0]),
+                      np.array([5.0]), torch.tensor([0.0])))             # pathology missing -> skipped
+    res, cidx = summary_survival(model, loader, meta["K"], "path", loss_fn=NLLSurvLoss(alpha=0.0))
+    n = len(loader) - 1
+    assert len(res["risk"]) == n and list(res["subject_id"]) == [0] + list(range(2, n + 1))
+    want = []
+    with torch.no_grad():
+        for b in loader:
+            if b[1].shape == (1, 1):
+                continue
+            hz, S, _, _ = model(path_features=b[1].cuda())
+            want.append(float(-S.sum()))
+    np.testing.assert_allclose(res["risk"], np.array(want), rtol=0, atol=1e-6)
+    t = np.concatenate([b[4] for b in loader if b[1].shape != (1, 1)])
+    c = np.array([float(b[5]) for b in loader if b[1].shape != (1, 1)])
+    assert abs(cidx - concordance_index_censored((1 - c).astype(bool), t, np.array(want))[0]) < 1e-12
