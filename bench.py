@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--cpu-bags", type=int, default=8, help="timed bags of the CPU baseline sample")
     ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
     ap.add_argument("--graph", action="store_true", help="also time N = 1k / 10k as captured hipGraph steps (extra key)")
-    ap.add_argument("--h2d", action="store_true", help="also report the PCIe-inclusive rate (extra key, never `value`)")
+    ap.add_argument("--h2d", action="store_true", default=True,
+                    help="also report the PCIe-inclusive rate (extra key `pcie_inclusive`, never `value`); on by default at N = 1")
+    ap.add_argument("--no-h2d", dest="h2d", action="store_false")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the bag and saved activations; f32 is the BASELINE metric, bf16 is config 5 "
                          "(bf16 MFMA, fp32 accumulate/epilogues; HBM roofline)")

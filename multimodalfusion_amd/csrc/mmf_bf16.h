@@ -14,7 +14,6 @@ namespace mmf {
 
 typedef unsigned short bf16_t;   // storage type (raw bits)
 
-#ifdef __HIPCC__
 __device__ inline float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ inline bf16_t f2bf(float f) {            // round to nearest even (v_cvt_pk_bf16_f32)
   __bf16 h = (__bf16)f;
@@ -36,7 +35,6 @@ __device__ inline float4 pack8(const float (&o)[8]) {
                      __uint_as_float(pack2(o[4], o[5])), __uint_as_float(pack2(o[6], o[7])));
 }
 __device__ inline uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2(a, b), pack2(c, d)); }
-#endif
 
 struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  transpose 1: dst[c][c0 + r];
                            // transpose 2: dst[c][c0 + 64 (r / 32) + r % 32]  (K-dh's interleaved [Wa-block | Wb-block] k order)
