@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # a run pays ~1 ms once (clocks ramp up after the sync): keep it < 2 %
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--bag", type=int, default=50000, help="instances per bag (BASELINE metric: 50000)")
     ap.add_argument("--eval-mode", action="store_true", help="no dropout (secondary figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,12 +78,13 @@ def make_step(model, x, dev, flat=None, world=1):
     Y = torch.tensor([1], device=dev)
     c = torch.tensor([0.0], device=dev)
     inv = 1.0 / world
+    params = list(model.parameters())
 
     def step():
         if flat is not None:
             flat.zero_()
         else:
-            for p in model.parameters():
+            for p in params:
                 p.grad = None
         hazards, S, Y_hat, _ = model(path_features=x)
         loss = loss_fn(hazards=hazards, S=S, Y=Y, c=c)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.utils import initialize_weights
-from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack
+from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack, amil_stack_head
 
 
 class MIL_Attention_fc_path(nn.Module):
@@ -40,10 +40,7 @@ class MIL_Attention_fc_surv_path(MIL_Attention_fc_path):
 
     def forward(self, **kwargs):
         h = kwargs["path_features"]
-        M, A_raw = amil_stack(self.attention_net_WSI, h, self.training)
-        if kwargs.get("return_features"):
-            return M
-        if kwargs.get("attention_only"):
-            return A_raw
-        hazards, S, Y_hat = ops.surv_head(M, self.classifier.weight, self.classifier.bias)
-        return hazards, S, Y_hat, A_raw
+        if kwargs.get("return_features") or kwargs.get("attention_only"):
+            M, A_raw = amil_stack(self.attention_net_WSI, h, self.training)
+            return M if kwargs.get("return_features") else A_raw
+        return amil_stack_head(self.attention_net_WSI, self.classifier, h, self.training)

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.utils import initialize_weights
-from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack
+from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack, amil_stack_head
 
 
 class MIL_Attention_fc_radio(nn.Module):
@@ -60,12 +60,9 @@ class MIL_Attention_fc_surv_radio(MIL_Attention_fc_radio):
             h = ops.linear_cat(h, self.reduce_dim.weight, self.reduce_dim.bias)   # cat(axis=1) + reduce_dim
         else:
             h = h[0]
-        M, A_raw = amil_stack(self.attention_net_radio, h, self.training)
-        if kwargs.get("attention_only"):
-            return A_raw
-        if kwargs.get("return_features"):
-            return M
-        if kwargs.get("return_attention"):
-            return A_raw
-        hazards, S, Y_hat = ops.surv_head(M, self.classifier.weight, self.classifier.bias)
-        return hazards, S, Y_hat, A_raw
+        if kwargs.get("attention_only") or kwargs.get("return_features") or kwargs.get("return_attention"):
+            M, A_raw = amil_stack(self.attention_net_radio, h, self.training)
+            if kwargs.get("attention_only"):
+                return A_raw
+            return M if kwargs.get("return_features") else A_raw
+        return amil_stack_head(self.attention_net_radio, self.classifier, h, self.training)

@@ -233,3 +233,16 @@ def amil_stack(seq, x, training):
     p_att = 0.25 if (training and att.att_dropout) else 0.0
     seed = ops.next_dropout_seed() if training else 0
     return ops.amil_pool(x, lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
+
+
+def amil_stack_head(seq, classifier, x, training):
+    """amil_stack followed by the classifier / hazard head as one autograd node -> (hazards, S, Y_hat, A_raw)."""
+    from .. import ops
+    lin, att = seq[0], seq[3]
+    gated = isinstance(att, Attn_Net_Gated)
+    Wa, ba, Wb, bb, Wc, bc = att.stack_params()
+    p_h = seq[2].p if training else 0.0
+    p_att = 0.25 if (training and att.att_dropout) else 0.0
+    seed = ops.next_dropout_seed() if training else 0
+    return ops.amil_head(x, lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc, classifier.weight, classifier.bias,
+                         gated, p_h, p_att, seed)

@@ -130,6 +130,86 @@ def amil_pool(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h=0.0, p_att=0.0, seed
     return AmilPoolFn.apply(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
 
 
+class AmilHeadFn(torch.autograd.Function):
+    """Attention stack + classifier/hazard head as ONE autograd node (models/model_attention_mil_path.py:52-61):
+    (x, stack params, Wk, bk) -> (hazards, S, Y_hat, A_raw).  Same kernels as AmilPoolFn + SurvHeadFn; one node less
+    on a path where a 1k-10k bag step is bound by host dispatch (tools/host_split2.py)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h, p_att, seed):
+        bf16 = x.dtype == torch.bfloat16
+        x = x.contiguous() if bf16 else _f32c(x)
+        N, L = x.shape
+        H, D, K = W1.shape[0], Wa.shape[0], Wk.shape[0]
+        if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D or Wk.shape[1] != H:
+            raise _lib.MmfError("attention stack / classifier shapes do not match the bag")
+        seed = int(seed) & 0xFFFFFFFF
+        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=seed)
+        l = lib()
+        ws_fn, fwd_fn = ((l.mmf_amil_bf16_workspace_bytes, l.mmf_amil_bf16_forward) if bf16
+                         else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
+        nbytes = ws_fn(N, L, H, D, d.gated)
+        dev = x.device
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        M = torch.empty((1, H), dtype=torch.float32, device=dev)
+        A_raw = torch.empty((1, N), dtype=torch.float32, device=dev)
+        st = stream_ptr()
+        check(fwd_fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), st), "mmf_amil_forward")
+        out = torch.empty((3, 1, K), dtype=torch.float32, device=dev)        # logits, hazards, S
+        Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
+        check(l.mmf_surv_head_forward(ptr(M), ptr(Wk), ptr(bk), 1, H, K, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                      ptr(Y_hat), st), "mmf_surv_head_forward")
+        ctx.cfg = (N, L, H, D, K, bool(gated), float(p_h), float(p_att), seed, bf16)
+        ctx.ws = ws
+        ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, M, A_raw, out)
+        ctx.mark_non_differentiable(Y_hat)
+        return out[1], out[2], Y_hat, A_raw
+
+    @staticmethod
+    def backward(ctx, gH, gS, _gY, gA):
+        x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, M, A_raw, out = ctx.saved_tensors
+        N, L, H, D, K, gated, p_h, p_att, seed, bf16 = ctx.cfg
+        if bf16 and ctx.needs_input_grad[0]:
+            raise _lib.MmfError("a bf16 bag is a leaf: no input gradient on the bf16 path")
+        dev = x.device
+        l = lib()
+        st = stream_ptr()
+        gH = _f32c(gH) if gH is not None else None
+        gS = _f32c(gS) if gS is not None else None
+        gA = _f32c(gA) if gA is not None else None
+        dM = torch.empty((1, H), dtype=torch.float32, device=dev)
+        dWk = torch.empty_like(Wk)
+        dbk = torch.empty((K,), dtype=torch.float32, device=dev)
+        check(l.mmf_surv_head_backward(ptr(gH), ptr(gS), ptr(out[1]), ptr(M), ptr(Wk), 1, H, K,
+                                       ptr(dM), ptr(dWk), ptr(dbk), st), "mmf_surv_head_backward")
+        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                     Wc=ptr(Wc), bc=ptr(bc), p_h=p_h, p_att=p_att, seed=seed)
+        new = torch.empty_like
+        dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
+        dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g = AmilGrads(dW1=ptr(dW1), db1=ptr(db1), dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb), dbb=ptr(dbb),
+                      dWc=ptr(dWc), dbc=ptr(dbc), dx=ptr(dx))
+        ws = ctx.ws
+        bwd_fn = l.mmf_amil_bf16_backward if bf16 else l.mmf_amil_backward
+        check(bwd_fn(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(M), ptr(A_raw), ptr(dM), ptr(gA), C.byref(g), st),
+              "mmf_amil_backward")
+        return dx, dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, dWk, dbk, None, None, None, None
+
+
+def amil_head(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h=0.0, p_att=0.0, seed=0):
+    if not torch.is_grad_enabled() and p_h == 0.0 and p_att == 0.0:       # inference consumers: no-save kernels
+        M, A_raw = amil_infer(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated)
+        hz, S, Y_hat = surv_head(M, Wk, bk)
+        return hz, S, Y_hat, A_raw
+    return AmilHeadFn.apply(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h, p_att, seed)
+
+
 class LinearCatFn(torch.autograd.Function):
     """y = cat(xs, dim=1) @ W.T + b without materialising the concatenation
     (models/model_attention_mil_radio.py:80-82)."""
@@ -228,17 +308,17 @@ class NllSurvFn(torch.autograd.Function):
         Y = Y.reshape(B).to(torch.int64).contiguous()
         c = c.reshape(B).to(torch.float32).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=hazards.device)
-        gH = torch.empty_like(hazards)
-        gS = torch.empty_like(S)
+        g = torch.empty((2, B, K), dtype=torch.float32, device=hazards.device)     # [d/d hazards ; d/d S]
         check(lib().mmf_nll_surv(ptr(hazards), ptr(S), ptr(Y), ptr(c), B, K, float(alpha), float(eps),
-                                 ptr(loss), ptr(gH), ptr(gS), stream_ptr()), "mmf_nll_surv")
-        ctx.save_for_backward(gH, gS)
+                                 ptr(loss), ptr(g[0]), ptr(g[1]), stream_ptr()), "mmf_nll_surv")
+        ctx.save_for_backward(g)
         return loss
 
     @staticmethod
-    def backward(ctx, g):
-        gH, gS = ctx.saved_tensors
-        return gH * g, gS * g, None, None, None, None
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        out = g * gl                      # one launch for both
+        return out[0], out[1], None, None, None, None
 
 
 def nll_surv(hazards, S, Y, c, alpha=0.4, eps=1e-7):
