@@ -42,16 +42,22 @@ class MaxNet(MaxNet_base):
 
     def forward(self, **kwargs):
         x = kwargs["genomic_features"]
-        features = snn_stack(self.fc_omic, x, self.training)
         if kwargs.get("return_features"):
-            return features
+            return snn_stack(self.fc_omic, x, self.training)
+        # SNN blocks + classifier as one autograd node (block i uses dropout site i, as snn_stack does)
+        tr = self.training
+        layers = [(blk[0].weight, blk[0].bias, "selu", "alpha" if tr else "none", blk[2].p if tr else 0.0, i)
+                  for i, blk in enumerate(self.fc_omic)]
+        seed = ops.next_dropout_seed() if tr else 0
         if "nll" in self.bag_loss:
             # The reference unsqueezes to [1 x B x K] and then takes topk / cumprod over dim=1, i.e. over the
             # BATCH axis (model_genomic.py:63-69).  Reproduced as is: hazards come from the HIP dense kernel,
             # the two degenerate axis ops are plain tensor ops on a [1 x B x K] view.
-            hazards = ops.dense(features, self.classifier.weight, self.classifier.bias, act="sigmoid").unsqueeze(0)
+            layers.append((self.classifier.weight, self.classifier.bias, "sigmoid", "none", 0.0, 0))
+            hazards = ops.mlp(x, layers, seed).unsqueeze(0)
             Y_hat = torch.topk(hazards.detach(), 1, dim=1)[1]   # sigmoid is monotone: same indices as topk(logits)
             S = torch.cumprod(1 - hazards, dim=1)
             return hazards, S, Y_hat, None
-        risk = ops.dense(features, self.classifier.weight, self.classifier.bias).squeeze()
+        layers.append((self.classifier.weight, self.classifier.bias, "none", "none", 0.0, 0))
+        risk = ops.mlp(x, layers, seed).squeeze()
         return risk, None, None, None

@@ -476,6 +476,48 @@ def _dense_bwd_raw(gy, y, x, W, has_bias, act, kind, p, seed, site, need_dx=True
     return dx, dW, db
 
 
+class MlpFn(torch.autograd.Function):
+    """A chain of dense layers as ONE autograd node (the omic head: SNN blocks + classifier,
+    models/model_genomic.py:56-72): same dense kernels, one Python forward / backward instead of one per layer.
+    spec: tuple of (act, drop_kind, drop_p, site) per layer; tensors: x, then (W, b) per layer."""
+
+    @staticmethod
+    def forward(ctx, spec, seed, x, *wb):
+        x = _f32c(x)
+        seed = int(seed) & 0xFFFFFFFF
+        acts = [x]
+        for i, (act, kind, p, site) in enumerate(spec):
+            acts.append(_dense_fwd_raw(acts[-1], wb[2 * i], wb[2 * i + 1], act, kind, p, seed, site))
+        ctx.cfg = (spec, seed)
+        ctx.save_for_backward(*acts, *wb)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, seed = ctx.cfg
+        n = len(spec)
+        t = ctx.saved_tensors
+        acts, wb = t[:n + 1], t[n + 1:]
+        g = _f32c(g)
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            act, kind, p, site = spec[i]
+            need_dx = i > 0 or ctx.needs_input_grad[2]
+            g, dW, db = _dense_bwd_raw(g, acts[i + 1], acts[i], wb[2 * i], wb[2 * i + 1] is not None, act, kind, p, seed,
+                                       site, need_dx=need_dx)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+        return (None, None, g) + tuple(grads)
+
+
+def mlp(x, layers, seed=0):
+    """layers: list of (W, b, act, drop_kind, drop_p, site)."""
+    spec = tuple((a, k, float(p), int(s)) for (_, _, a, k, p, s) in layers)
+    wb = []
+    for (W, b, *_r) in layers:
+        wb += [W, b]
+    return MlpFn.apply(spec, seed, x, *wb)
+
+
 class XFusionFn(torch.autograd.Function):
     """The whole XlinearFusion block (models/model_modules.py:156-178, gate=1, skip=1) as ONE autograd node: the same
     HIP kernels as the composable ops above, but one Python forward and one Python backward instead of ~25 nodes
