@@ -157,3 +157,37 @@ def test_dense_odd_shapes():
         np.testing.assert_allclose(y.detach().cpu().numpy(), ry.detach().numpy(), atol=2e-5, rtol=1e-5)
         for a, r in ((tx, rx), (tW, rW), (tb, rb)):
             np.testing.assert_allclose(a.grad.cpu().numpy(), r.grad.numpy(), atol=2e-5, rtol=1e-4)
+
+
+def test_mm_side_stream_branches_give_identical_results():
+    """Big fp32 path bags run the radio / omic branches on a second HIP stream (model_mm_attention_mil.py: _side_stream);
+    outputs and every gradient must be bit-identical to the single-stream run."""
+    from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    m = dict(fusion="tensor", mode="radio_path_omic", Np=31000, nr=96, G=80, gate_path=True, gate_radio=True, K=4,
+             seed=5, x_seed=6, y=1, c=0, alpha=0.0, bias_std=0.02)
+    sd, xs, xp, xo = cases.mm_inputs(m)
+    outs = []
+    for side in (True, False):
+        model = _load(MM_MIL_Attention_fc_surv(input_dim=80, radio_fusion="concat", fusion="tensor", gate=True,
+                                               gate_path=True, gate_omic=True, gate_radio=True, n_classes=4,
+                                               mode=m["mode"]), sd).eval()
+        model.mmf_side_stream = side
+        kw = {k: _t(x) for k, x in zip(cases.MODS, xs)}
+        kw["path_features"] = _t(xp)
+        kw["genomic_features"] = _t(xo)
+        for _ in range(2):                      # second pass: the side stream already exists, buffers get recycled
+            for p in model.parameters():
+                p.grad = None
+            hz, S, Yh, A_raw = model(**kw)
+            loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.0], device=DEV))
+            loss.backward()
+        torch.cuda.synchronize()
+        outs.append((hz.detach().clone(), {k: v.detach().clone() for k, v in A_raw.items()},
+                     {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    (h1, a1, g1), (h2, a2, g2) = outs
+    assert torch.equal(h1, h2)
+    for k in a1:
+        assert torch.equal(a1[k], a2[k]), k
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
