@@ -198,64 +198,89 @@ __device__ inline DropSpec site_drop(const DropSpec& d, int i) {
   r.key = d.key + 0x632BE5ABu * (uint32_t)i;
   return r;
 }
+// dot of two length-n vectors (n % 4 == 0, 16-byte aligned) across a wave; float4 loads, all issued before the adds
 __device__ inline float wave_dot(const float* a, const float* b, int n, int lane) {
   float acc = 0.f;
-  for (int k = lane; k < n; k += 64) acc += a[k] * b[k];
-  return wave_sum(acc);
+#pragma unroll 4
+  for (int k = 4 * lane; k < n; k += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(a + k), w = *reinterpret_cast<const float4*>(b + k);
+    acc += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
+  }
+  return acc;                         // caller reduces: several partial dots are reduced together
 }
 
-__global__ __launch_bounds__(256) void xreduce_fwd_kernel(XReduceParams p) {
+constexpr int XR_NT = 1024;           // one workgroup of 16 waves: the stage is latency-bound, so width = parallel loads
+
+__global__ __launch_bounds__(XR_NT) void xreduce_fwd_kernel(XReduceParams p) {
   __shared__ float sh_h[XR_MAX], sh_z[XR_MAX], sh_gm[XR_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = XR_NT / 64;
   const int S = p.sdim, per = p.B * S, total = p.m * per;
-  // h and z: one wave per output value
-  for (int o = wave; o < 2 * total; o += 4) {
-    const bool is_z = o >= total;
-    const int q = is_z ? o - total : o;
-    const int i = q / per, b = (q % per) / S, j = q % S;
-    float acc;
-    if (!is_z) {
-      acc = wave_dot(p.v[i] + (size_t)b * p.dim, p.Wh[i] + (size_t)j * p.dim, p.dim, lane) + p.bh[i][j];
-      acc = fmaxf(acc, 0.f);
-    } else {
-      acc = 0.f;
-      for (int t = 0; t < p.m; ++t)      // v_cat = [v_0 | v_1 | ...]
-        acc += wave_dot(p.v[t] + (size_t)b * p.dim, p.Wz[i] + (size_t)j * p.m * p.dim + (size_t)t * p.dim, p.dim, lane);
-      acc += p.bz[i][j];
+  // h and z: one wave per output value, 4 outputs per wave in flight (independent loads, then 4 reductions)
+  for (int o0 = wave; o0 < 2 * total; o0 += 4 * NW) {
+    float acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * NW;
+      acc[u] = 0.f;
+      if (o < 2 * total) {
+        const bool is_z = o >= total;
+        const int q = is_z ? o - total : o;
+        const int i = q / per, b = (q % per) / S, j = q % S;
+        if (!is_z) {
+          acc[u] = wave_dot(p.v[i] + (size_t)b * p.dim, p.Wh[i] + (size_t)j * p.dim, p.dim, lane);
+        } else {
+          for (int t = 0; t < p.m; ++t)      // v_cat = [v_0 | v_1 | ...]
+            acc[u] += wave_dot(p.v[t] + (size_t)b * p.dim, p.Wz[i] + (size_t)j * p.m * p.dim + (size_t)t * p.dim, p.dim, lane);
+        }
+      }
     }
-    if (lane == 0) (is_z ? sh_z : sh_h)[q] = acc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * NW;
+      const float r = wave_sum(acc[u]);
+      if (o < 2 * total && lane == 0) {
+        const bool is_z = o >= total;
+        const int q = is_z ? o - total : o;
+        const int i = q / per, j = q % S;
+        if (is_z) sh_z[q] = r + p.bz[i][j];
+        else sh_h[q] = fmaxf(r + p.bh[i][j], 0.f);
+      }
+    }
   }
   __syncthreads();
-  for (int q = tid; q < total; q += 256) {
+  for (int q = tid; q < total; q += XR_NT) {
     const int i = q / per, r = q % per;
     const float g = (1.0f / (1.0f + expf(-sh_z[q]))) * sh_h[q];
     sh_gm[q] = g;
     p.h[i][r] = sh_h[q]; p.z[i][r] = sh_z[q]; p.gm[i][r] = g;
   }
   __syncthreads();
-  for (int q = tid; q < total; q += 256) {
+  for (int q = tid; q < total; q += XR_NT) {
     const int i = q / per, r = q % per, b = r / S, j = r % S;
     float acc = p.bo[i][j];
+#pragma unroll 16
     for (int t = 0; t < S; ++t) acc += sh_gm[i * per + b * S + t] * p.Wo[i][j * S + t];
     acc = fmaxf(acc, 0.f);
     p.o[i][r] = drop_fwd(acc, site_drop(p.drop, i), (uint32_t)r);
   }
 }
 
-__global__ __launch_bounds__(256) void xreduce_bwd_kernel(XReduceParams p) {
+__global__ __launch_bounds__(XR_NT) void xreduce_bwd_kernel(XReduceParams p) {
   __shared__ float sh_dpo[XR_MAX], sh_dgm[XR_MAX], sh_dz[XR_MAX], sh_dph[XR_MAX];
   const int tid = threadIdx.x;
   const int S = p.sdim, per = p.B * S, total = p.m * per, KZ = p.m * p.dim;
-  for (int q = tid; q < total; q += 256) {         // d(pre-activation of o)
+  for (int q = tid; q < total; q += XR_NT) {       // d(pre-activation of o)
     const int i = q / per, r = q % per;
     float dydy, y;
     drop_bwd(p.o[i][r], site_drop(p.drop, i), (uint32_t)r, dydy, y);
     sh_dpo[q] = p.d_o[i][r] * dydy * (y > 0.f ? 1.f : 0.f);
   }
   __syncthreads();
-  for (int q = tid; q < total; q += 256) {         // d gm = dpo . Wo ; then dz, dh
+  for (int q = tid; q < total; q += XR_NT) {       // d gm = dpo . Wo ; then dz, dh
     const int i = q / per, r = q % per, b = r / S, t = r % S;
     float acc = 0.f;
+#pragma unroll 16
     for (int j = 0; j < S; ++j) acc += sh_dpo[i * per + b * S + j] * p.Wo[i][j * S + t];
     sh_dgm[q] = acc;
     const float hv = p.h[i][r], sg = 1.0f / (1.0f + expf(-p.z[i][r]));
@@ -264,51 +289,56 @@ __global__ __launch_bounds__(256) void xreduce_bwd_kernel(XReduceParams p) {
   }
   __syncthreads();
   // small weight grads: dWo [S x S], dbo, dbh, dbz
-  for (int q = tid; q < p.m * S * S; q += 256) {
+  for (int q = tid; q < p.m * S * S; q += XR_NT) {
     const int i = q / (S * S), j = (q / S) % S, t = q % S;
     float acc = 0.f;
     for (int b = 0; b < p.B; ++b) acc += sh_dpo[i * per + b * S + j] * p.gm[i][b * S + t];
     p.dWo[i][j * S + t] = acc;
   }
-  for (int q = tid; q < p.m * S; q += 256) {
+  for (int q = tid; q < p.m * S; q += XR_NT) {
     const int i = q / S, j = q % S;
     float a = 0.f, bsum = 0.f, c = 0.f;
     for (int b = 0; b < p.B; ++b) { a += sh_dpo[i * per + b * S + j]; bsum += sh_dph[i * per + b * S + j]; c += sh_dz[i * per + b * S + j]; }
     p.dbo[i][j] = a; p.dbh[i][j] = bsum; p.dbz[i][j] = c;
   }
-  // dWh [S x dim], dWz [S x m*dim], dv [B x dim]: threads along the long dimension
-  for (int i = 0; i < p.m; ++i) {
-    for (int q = tid; q < S * p.dim; q += 256) {
-      const int j = q / p.dim, k = q % p.dim;
-      float acc = 0.f;
-      for (int b = 0; b < p.B; ++b) acc += sh_dph[i * per + b * S + j] * p.v[i][(size_t)b * p.dim + k];
-      p.dWh[i][q] = acc;
-    }
-    for (int q = tid; q < S * KZ; q += 256) {
-      const int j = q / KZ, k = q % KZ, t = k / p.dim, kk = k % p.dim;
-      float acc = 0.f;
-      for (int b = 0; b < p.B; ++b) acc += sh_dz[i * per + b * S + j] * p.v[t][(size_t)b * p.dim + kk];
-      p.dWz[i][q] = acc;
-    }
+  // dWh [S x dim], dWz [S x m*dim]: outer products with v, threads along the long dimension (pure stores for B = 1)
+  for (int q = tid; q < p.m * S * p.dim; q += XR_NT) {
+    const int i = q / (S * p.dim), jk = q % (S * p.dim), j = jk / p.dim, k = jk % p.dim;
+    float acc = 0.f;
+    for (int b = 0; b < p.B; ++b) acc += sh_dph[i * per + b * S + j] * p.v[i][(size_t)b * p.dim + k];
+    p.dWh[i][jk] = acc;
   }
-  for (int q = tid; q < p.m * p.B * p.dim; q += 256) {      // dv_t = dph_t . Wh_t + sum_i dz_i . Wz_i[:, t-th block]
+  for (int q = tid; q < p.m * S * KZ; q += XR_NT) {
+    const int i = q / (S * KZ), jk = q % (S * KZ), j = jk / KZ, k = jk % KZ, t = k / p.dim, kk = k % p.dim;
+    float acc = 0.f;
+    for (int b = 0; b < p.B; ++b) acc += sh_dz[i * per + b * S + j] * p.v[t][(size_t)b * p.dim + kk];
+    p.dWz[i][jk] = acc;
+  }
+  // dv_t = dph_t . Wh_t + sum_i dz_i . Wz_i[:, t-th block]: (1 + m) * S independent, coalesced loads per output
+  for (int q = tid; q < p.m * p.B * p.dim; q += XR_NT) {
     const int t = q / (p.B * p.dim), b = (q / p.dim) % p.B, k = q % p.dim;
     float acc = 0.f;
+#pragma unroll 16
     for (int j = 0; j < S; ++j) acc += sh_dph[t * per + b * S + j] * p.Wh[t][(size_t)j * p.dim + k];
-    for (int i = 0; i < p.m; ++i)
-      for (int j = 0; j < S; ++j) acc += sh_dz[i * per + b * S + j] * p.Wz[i][(size_t)j * KZ + (size_t)t * p.dim + k];
+    for (int i = 0; i < p.m; ++i) {
+      float a2 = 0.f;
+#pragma unroll 16
+      for (int j = 0; j < S; ++j) a2 += sh_dz[i * per + b * S + j] * p.Wz[i][(size_t)j * KZ + (size_t)t * p.dim + k];
+      acc += a2;
+    }
     p.dv[t][(size_t)b * p.dim + k] = acc;
   }
 }
 
 int launch_xreduce_fwd(XReduceParams p, hipStream_t st) {
   if (p.m * p.B * p.sdim > XR_MAX || p.m < 1 || p.m > 3) return MMF_ERR_SHAPE;
-  { ProfScope ps("xreduce_fwd_kernel", st); hipLaunchKernelGGL(xreduce_fwd_kernel, dim3(1), dim3(256), 0, st, p); }
+  if (p.dim % 4 != 0) return MMF_ERR_SHAPE;
+  { ProfScope ps("xreduce_fwd_kernel", st); hipLaunchKernelGGL(xreduce_fwd_kernel, dim3(1), dim3(XR_NT), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 int launch_xreduce_bwd(XReduceParams p, hipStream_t st) {
   if (p.m * p.B * p.sdim > XR_MAX || p.m < 1 || p.m > 3) return MMF_ERR_SHAPE;
-  { ProfScope ps("xreduce_bwd_kernel", st); hipLaunchKernelGGL(xreduce_bwd_kernel, dim3(1), dim3(256), 0, st, p); }
+  { ProfScope ps("xreduce_bwd_kernel", st); hipLaunchKernelGGL(xreduce_bwd_kernel, dim3(1), dim3(XR_NT), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
@@ -332,28 +362,35 @@ __device__ inline float dense_dpre_at(const DenseBwdParams& p, int b, int n) {
   drop_bwd(p.y[o], p.drop, (uint32_t)o, dydy, y);
   return p.dy[o] * dydy * act_grad_from_y(y, p.act);
 }
-__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdParams p, int nbx, int dx_blocks) {
+__global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdParams p, int nbx, int dx_blocks, int nbw) {
   __shared__ float sh[DENSE_MAX_N];
   const int tid = threadIdx.x;
   int id = blockIdx.x;
   if (id < dx_blocks) {                       // ---- dx[b][k] = sum_n dpre[b][n] W[n][k]
-    const int b = id / nbx, k = (id % nbx) * 256 + tid;
+    // 64 k-columns x 4 n-slices per block: 4x more blocks and 4x shorter load chains than one thread per column
+    // (the layer is latency-bound: B = 1, a handful of blocks, hundreds of dependent-address loads each)
+    __shared__ float part[4][64];
+    const int b = id / nbx, kl = tid & 63, sl = tid >> 6, k = (id % nbx) * 64 + kl;
     for (int n = tid; n < p.N; n += 256) sh[n] = dense_dpre_at(p, b, n);
     __syncthreads();
-    if (k >= p.K) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int n = 0;
-    for (; n + 3 < p.N; n += 4) {
-      a0 += sh[n] * p.W[(size_t)n * p.K + k];
-      a1 += sh[n + 1] * p.W[(size_t)(n + 1) * p.K + k];
-      a2 += sh[n + 2] * p.W[(size_t)(n + 2) * p.K + k];
-      a3 += sh[n + 3] * p.W[(size_t)(n + 3) * p.K + k];
+    if (k < p.K) {
+      const int n0 = sl * ((p.N + 3) / 4), n1 = n0 + (p.N + 3) / 4 < p.N ? n0 + (p.N + 3) / 4 : p.N;
+      int n = n0;
+      for (; n + 3 < n1; n += 4) {
+        a0 += sh[n] * p.W[(size_t)n * p.K + k];
+        a1 += sh[n + 1] * p.W[(size_t)(n + 1) * p.K + k];
+        a2 += sh[n + 2] * p.W[(size_t)(n + 2) * p.K + k];
+        a3 += sh[n + 3] * p.W[(size_t)(n + 3) * p.K + k];
+      }
+      for (; n < n1; ++n) a0 += sh[n] * p.W[(size_t)n * p.K + k];
     }
-    for (; n < p.N; ++n) a0 += sh[n] * p.W[(size_t)n * p.K + k];
-    p.dx[(size_t)b * p.K + k] = (a0 + a1) + (a2 + a3);
+    part[sl][kl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && k < p.K) p.dx[(size_t)b * p.K + k] = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
   } else {                                    // ---- dW[n][k] = sum_b dpre[b][n] x[b][k] ; db[n] = sum_b dpre[b][n]
     id -= dx_blocks;
-    const int n = id / nbx, kb = id % nbx, k = kb * 256 + tid;
+    const int n = id / nbw, kb = id % nbw, k = kb * 256 + tid;
     if (tid < p.B) sh[tid] = dense_dpre_at(p, tid, n);
     __syncthreads();
     if (k < p.K) {
@@ -372,12 +409,12 @@ __global__ __launch_bounds__(256) void dense_bwd_kernel(DenseBwdParams p, int nb
 int launch_dense_bwd(DenseBwdParams p, hipStream_t st) {
   const int64_t total = (int64_t)p.B * p.N;
   if (p.N <= DENSE_MAX_N && p.B <= DENSE_MAX_B) {
-    const int nbx = cdiv(p.K, 256);
+    const int nbx = cdiv(p.K, 64), nbw = cdiv(p.K, 256);        // dx: 64 columns per block; dW: 256 per block
     const int dx_blocks = p.dx ? nbx * p.B : 0;
-    const int dw_blocks = p.dW ? nbx * p.N : 0;
+    const int dw_blocks = p.dW ? nbw * p.N : 0;
     if (dx_blocks + dw_blocks == 0) return MMF_OK;
     { ProfScope ps("dense_bwd_kernel", st);
-      hipLaunchKernelGGL(dense_bwd_kernel, dim3(dx_blocks + dw_blocks), dim3(256), 0, st, p, nbx, dx_blocks); }
+      hipLaunchKernelGGL(dense_bwd_kernel, dim3(dx_blocks + dw_blocks), dim3(256), 0, st, p, nbx, dx_blocks, nbw); }
     return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
   }
   { ProfScope ps("dense_dpre_kernel", st); hipLaunchKernelGGL(dense_dpre_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p); }
