@@ -158,13 +158,12 @@ def graph_leg(model, dev, steps, gen):
     res = {}
     for n in (1000, 10000):
         x = torch.randn(n, 1024, device=dev, generator=gen)
-        for p in model.parameters():
-            p.grad = torch.zeros_like(p)
+        params = list(model.parameters())
 
         def fn():
-            for p in model.parameters():
-                p.grad.zero_()
-            hz, S, Yh, _ = model(path_features=x)
+            for p in params:
+                p.grad = None          # gradients are (re)allocated from the graph's private pool: static addresses,
+            hz, S, Yh, _ = model(path_features=x)   # no zero-fill and no accumulate kernels in the captured step
             loss = loss_fn(hazards=hz, S=S, Y=Y, c=c)
             loss.backward()
             return loss
