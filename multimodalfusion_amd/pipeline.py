@@ -1,0 +1,91 @@
+"""Several bags in flight on one GPU.
+
+The reference trains with batch_size = 1 and gradient accumulation (`--gc`, utils/core_utils.py:242-247): the bags of
+one accumulation window are independent until the optimizer step.  One bag's kernels do not fill an MI355X all the
+time -- the row-parallel GEMMs run 224 workgroups on 256 CUs, every kernel has a tail, the small kernels are latency
+-- so the window's bags are issued round-robin on a few HIP streams and the hardware overlaps them
+(measured at 50k x 1024 fp32: 1090 -> 1205 bags/s with two streams; 100k bf16: 2024 -> 2607).
+
+Each stream owns a gradient slot (one flat fp32 buffer): a bag's gradients are written to ITS stream's slot, so two
+backward passes never touch the same memory; `reduce()` joins the streams and sums the slots (and all-reduces over
+ranks when torch.distributed is initialised).  Results are bit-identical to running the same bags one after the other
+into per-bag buffers (tests/test_gpu_pipeline.py).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class BagsInFlight:
+    def __init__(self, model: torch.nn.Module, n_streams: int = 2, device=None):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.device = self.params[0].device if device is None else torch.device(device)
+        self.n = max(1, int(n_streams))
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+        numel = sum(p.numel() for p in self.params)
+        self.slots = torch.zeros((self.n, numel), dtype=torch.float32, device=self.device)
+        self._count = 0
+        self._used = [False] * self.n
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def run(self, loss_fn_of_model_call, accumulate: bool = True):
+        """Issue one bag: `loss_fn_of_model_call()` must run the forward and return the scalar loss; its gradients are
+        added to (accumulate=True) or written over (False) the slot of the stream the bag runs on.  Returns the loss
+        (a tensor living on that stream; read it after `join()`)."""
+        i = self._count % self.n
+        self._count += 1
+        st = self.streams[i]
+        with torch.cuda.stream(st):
+            loss = loss_fn_of_model_call()
+            grads = torch.autograd.grad(loss, self.params)
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            if accumulate and self._used[i]:
+                self.slots[i].add_(flat)
+            else:
+                self.slots[i].copy_(flat)
+            self._used[i] = True
+        return loss
+
+    def all_reduce_slot(self, group=None):
+        """Multi-GPU benchmark helper: all-reduce the slot of the bag issued last, on its stream (the collective of
+        one bag overlaps with the other stream's kernels)."""
+        i = (self._count - 1) % self.n
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            with torch.cuda.stream(self.streams[i]):
+                dist.all_reduce(self.slots[i], op=dist.ReduceOp.SUM, group=group)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def reduce(self, group=None, all_reduce: bool = True) -> torch.Tensor:
+        """End of an accumulation window: join, sum the slots (fixed order), all-reduce over ranks; returns the flat
+        gradient (views of it can be handed to the optimizer, see assign_grads)."""
+        self.join()
+        used = [i for i in range(self.n) if self._used[i]]
+        total = self.slots[used[0]] if used else self.slots[0].zero_()
+        for i in used[1:]:
+            total.add_(self.slots[i])
+        if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        self._used = [False] * self.n
+        for s in self.streams:                       # the next window's bags must see the reduced / reset slots
+            s.wait_stream(torch.cuda.current_stream(self.device))
+        return total
+
+    def release(self):
+        """Call after the optimizer step that consumed `reduce()`'s result: the next window's bags (on the side
+        streams) must see the updated weights."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def assign_grads(self, flat: torch.Tensor):
+        off = 0
+        for p in self.params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()

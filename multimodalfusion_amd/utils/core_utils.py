@@ -66,9 +66,19 @@ def _skip(mode, radio_features, path_features, genomic_features):
 
 
 def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer=None, loss_fn=None, reg_fn=None,
-                        lambda_reg=0., gc=16, t_bin=None, dp=False, grad_buffer=None):
+                        lambda_reg=0., gc=16, t_bin=None, dp=False, grad_buffer=None, inflight=1):
+    """utils/core_utils.py:173-264.  Extras (all off by default): `dp` = one bag per rank with one all-reduce per
+    optimizer step; a `FlatAdam` optimizer = fused L1 + Adam tail; `inflight` > 1 (needs FlatAdam) = the bags of an
+    accumulation window run round-robin on that many HIP streams, each into its own gradient slot
+    (pipeline.BagsInFlight)."""
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     model.train()
+    pipe = None
+    if inflight > 1:
+        if not isinstance(optimizer, FlatAdam):
+            raise ValueError("inflight > 1 needs the FlatAdam optimizer (flat gradient buffer)")
+        from ..pipeline import BagsInFlight
+        pipe = BagsInFlight(model, inflight, device)
     world, rank = 1, 0
     if dp and torch.distributed.is_available() and torch.distributed.is_initialized():
         world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
@@ -82,16 +92,39 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
         if world > 1 and batch_idx % world != rank:
             continue
         feats, label, c = _to_device(radio_features, path_features, genomic_features, label, c, device)
-        hazards, S, Y_hat, _ = model(**feats)
-        if isinstance(loss_fn, CoxSurvLoss):
-            risk = hazards
-            loss = loss_fn(risks=risk, times=torch.as_tensor(np.asarray(event_time)), c=c)
-        elif isinstance(loss_fn, NLLSurvLoss):
-            risk = -torch.sum(S, dim=1)
-            loss = loss_fn(hazards=hazards, S=S, Y=label, c=c)
-        else:
+
+        def forward_loss():
+            hazards, S, Y_hat, _ = model(**feats)
+            if isinstance(loss_fn, CoxSurvLoss):
+                return hazards, loss_fn(risks=hazards, times=torch.as_tensor(np.asarray(event_time)), c=c)
+            if isinstance(loss_fn, NLLSurvLoss):
+                return -torch.sum(S, dim=1), loss_fn(hazards=hazards, S=S, Y=label, c=c)
             raise NotImplementedError(type(loss_fn))
+
         fused_tail = isinstance(optimizer, FlatAdam)
+        if pipe is not None:
+            box = {}
+
+            def bag():
+                box["risk"], box["loss"] = forward_loss()
+                return box["loss"] / (gc * world)
+
+            pipe.run(bag)
+            risk, loss = box["risk"], box["loss"]
+            loss_reg = optimizer.l1_value() if (reg_fn is not None and lambda_reg) else 0
+            losses.append(loss.detach())
+            regs.append(loss_reg.detach() if torch.is_tensor(loss_reg) else torch.tensor(float(loss_reg), device=device))
+            all_risk.append(risk.detach().reshape(-1))
+            all_c.append(c.detach().reshape(-1))
+            all_t.append(np.asarray(event_time).reshape(-1))
+            seen += 1
+            if seen % gc == 0:
+                optimizer.flat_g.copy_(pipe.reduce(all_reduce=world > 1))
+                optimizer.lambda_l1 = lambda_reg if reg_fn is not None else 0.0
+                optimizer.step(l1_micro_batches=gc * world)
+                pipe.release()
+            continue
+        risk, loss = forward_loss()
         if fused_tail:
             # fused per-step tail: the L1 term never enters autograd; its gradient (lambda * sign(W) per micro-batch)
             # is added inside the Adam kernel, its value is a device scalar for logging only

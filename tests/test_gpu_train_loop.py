@@ -138,3 +138,29 @@ def test_summary_survival_matches_per_bag_forward(golden):
     t = np.concatenate([b[4] for b in loader if b[1].shape != (1, 1)])
     c = np.array([float(b[5]) for b in loader if b[1].shape != (1, 1)])
     assert abs(cidx - concordance_index_censored((1 - c).astype(bool), t, np.array(want))[0]) < 1e-12
+
+
+def test_bags_in_flight_reproduce_the_reference_trajectory(golden):
+    """inflight=2: the two bags of each accumulation window run on two HIP streams into two gradient slots; the
+    parameters after each optimizer step are still the reference's (gc = 2 fixture)."""
+    from multimodalfusion_amd.optim import FlatAdam
+    from multimodalfusion_amd.utils import core_utils
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    from multimodalfusion_amd.utils.utils import l1_reg_all
+    g, meta, sd, model, loader = _setup(golden)
+    opt = FlatAdam(model, lr=meta["lr"], weight_decay=meta["reg"], lambda_l1=meta["lambda_reg"])
+    snaps = []
+    step0 = opt.step
+
+    def step(**kw):
+        step0(**kw)
+        snaps.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+
+    opt.step = step
+    out = core_utils.train_loop_survival(0, model, loader, opt, meta["K"], "path", loss_fn=NLLSurvLoss(alpha=0.0),
+                                         reg_fn=l1_reg_all, lambda_reg=meta["lambda_reg"], gc=meta["gc"], inflight=2)
+    np.testing.assert_allclose(out["losses"], g["f64/losses"], atol=1e-5)
+    assert len(snaps) == 2
+    for si, snap in enumerate(snaps, start=1):
+        for k, v in snap.items():
+            check_summary(g, f"f64/step{si}/{k}", v, rtol=2e-5, atol=2e-6)
