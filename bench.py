@@ -12,7 +12,7 @@ all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == the re
 Train mode as `model.train()` with --drop_out off (one Dropout(0.25) mask, the headline mode of
 BASELINE.md); rank 0 prints ONE JSON line.
 
-Steps are issued round-robin on `--inflight` HIP streams (default 2), each with its own flat gradient buffer
+Steps are issued round-robin on `--inflight` HIP streams (default 3), each with its own flat gradient buffer
 (multimodalfusion_amd/pipeline.py): bags are independent until the optimizer step (batch_size = 1 + gradient
 accumulation in the reference), and one bag's kernels leave CUs idle (224 of 256 in the row-parallel GEMMs, every
 kernel's tail, the latency-bound small kernels).  Every step is still one full forward + loss + backward of one bag
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--h2d", action="store_true", default=True,
                     help="also report the PCIe-inclusive rate (extra key `pcie_inclusive`, never `value`); on by default at N = 1")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="bags in flight per GPU: steps are issued round-robin on this many HIP streams, each with its "
                          "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
