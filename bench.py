@@ -49,9 +49,10 @@ def parse():
     ap.add_argument("--h2d", action="store_true", default=True,
                     help="also report the PCIe-inclusive rate (extra key `pcie_inclusive`, never `value`); on by default at N = 1")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="bags in flight per GPU: steps are issued round-robin on this many HIP streams, each with its "
-                         "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time")
+                         "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time; "
+                         "0 = default: 3 (fp32), 2 (bf16: its 0.4 ms steps become host-bound beyond two)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the bag and saved activations; f32 is the BASELINE metric, bf16 is config 5 "
                          "(bf16 MFMA, fp32 accumulate/epilogues; HBM roofline)")
@@ -359,7 +360,7 @@ def main():
     bf16 = args.dtype == "bf16"
     if bf16:
         x = x.to(torch.bfloat16)
-    inflight = max(1, args.inflight)
+    inflight = args.inflight if args.inflight > 0 else (2 if bf16 else 3)
     step = make_step(model, x, dev, flat, world) if inflight == 1 else make_step_inflight(model, x, dev, world, inflight)
 
     dt = time_steps(step, args.steps, args.warmup, world)
