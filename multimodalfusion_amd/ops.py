@@ -618,7 +618,6 @@ class BatchNormFn(torch.autograd.Function):
                                           stream_ptr()), "mmf_batchnorm_forward")
         ctx.cfg = (bool(training), act, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), res is not None)
         ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.mark_non_differentiable(running_mean, running_var) if running_mean is not None else None
         return y
 
     @staticmethod
