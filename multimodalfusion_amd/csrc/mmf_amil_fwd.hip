@@ -257,7 +257,21 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   const int cv = tid % VPR, rg = tid / VPR;
   float4 v = zero4();
   float lsum = 0.f;
-  for (int i = rg; i < nrows; i += RG) {
+  int i = rg;
+  for (; i + 3 * RG < nrows; i += 4 * RG) {        // 4 independent row loads in flight (the loop was latency-bound)
+    float4 hv[4];
+    float e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hv[u] = ld4(p.h + (size_t)(r0 + i + u * RG) * p.H + 4 * cv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = __expf(s_lds[i + u * RG] - m);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v.x += e[u] * hv[u].x; v.y += e[u] * hv[u].y; v.z += e[u] * hv[u].z; v.w += e[u] * hv[u].w;
+      if (cv == 0) lsum += e[u];
+    }
+  }
+  for (; i < nrows; i += RG) {
     float e = __expf(s_lds[i] - m);
     float4 hv = ld4(p.h + (size_t)(r0 + i) * p.H + 4 * cv);
     v.x += e * hv.x; v.y += e * hv.y; v.z += e * hv.z; v.w += e * hv.w;
