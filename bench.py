@@ -137,6 +137,10 @@ def make_step_inflight(model, x, dev, world, n_streams):
 def time_steps(step, steps, warmup, world):
     import torch
     import torch.distributed as dist
+    # untimed: bring the device to its steady clocks first (after an idle period the first ~1 ms of work runs at
+    # ramping clocks, which is 4 % of a 30-step run), then the W warm-up steps the caller asked for
+    for _ in range(40):          # a fixed count: with N > 1 every step holds a collective, all ranks must issue the same number
+        step()
     for _ in range(warmup):
         step()
     if world > 1:
