@@ -5,33 +5,25 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
 from ..utils.utils import initialize_weights
-from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack, amil_stack_head
+from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, make_amil_stack
 
 
 class MIL_Attention_fc_path(nn.Module):
+    """Parameter container: `attention_net_WSI` (the stack) and `classifier`; the arithmetic lives in the HIP kernels."""
+
     def __init__(self, gate_path=True, dropout=True, model_size_wsi: str = "small", n_classes=4):
         super().__init__()
-        self.size_dict_WSI = {"small": [1024, 256, 256], "big": [1024, 512, 384]}
-        size_WSI = self.size_dict_WSI[model_size_wsi]
-        fc_WSI = [nn.Linear(size_WSI[0], size_WSI[1]), nn.ReLU(), nn.Dropout(0.25)]
-        if gate_path:
-            attention_net_WSI = Attn_Net_Gated(L=size_WSI[1], D=size_WSI[2], dropout=dropout, n_classes=1)
-        else:
-            attention_net_WSI = Attn_Net(L=size_WSI[1], D=size_WSI[2], dropout=dropout, n_classes=1)
-        fc_WSI.append(attention_net_WSI)
-        self.attention_net_WSI = nn.Sequential(*fc_WSI)
-        self.classifier = nn.Linear(size_WSI[1], n_classes)
+        self.size_dict_WSI = {name: list(dims) for name, dims in AMIL_SIZES.items()}
+        self.attention_net_WSI = make_amil_stack(model_size_wsi, gated=gate_path, att_dropout=dropout)
+        self.classifier = nn.Linear(AMIL_SIZES[model_size_wsi][1], n_classes)
         initialize_weights(self)
 
     def relocate(self):
-        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.attention_net_WSI = self.attention_net_WSI.to(device)
-        self.classifier = self.classifier.to(device)
+        self.to(torch.device("cuda" if torch.cuda.is_available() else "cpu"))
 
     def forward(self, h, return_features=False, attention_only=False):
-        pass
+        pass            # abstract in the reference too (:42-43)
 
 
 class MIL_Attention_fc_surv_path(MIL_Attention_fc_path):
@@ -39,8 +31,10 @@ class MIL_Attention_fc_surv_path(MIL_Attention_fc_path):
         super().__init__(gate_path=gate_path, model_size_wsi=model_size_wsi, dropout=dropout, n_classes=n_classes)
 
     def forward(self, **kwargs):
-        h = kwargs["path_features"]
-        if kwargs.get("return_features") or kwargs.get("attention_only"):
-            M, A_raw = amil_stack(self.attention_net_WSI, h, self.training)
-            return M if kwargs.get("return_features") else A_raw
-        return amil_stack_head(self.attention_net_WSI, self.classifier, h, self.training)
+        bag = kwargs["path_features"]
+        want_embedding, want_scores = kwargs.get("return_features"), kwargs.get("attention_only")
+        if want_embedding or want_scores:
+            M, A_raw = amil_stack(self.attention_net_WSI, bag, self.training)
+            return M if want_embedding else A_raw
+        # (hazards, S, Y_hat, A_raw): stack + classifier + hazard head as one autograd node
+        return amil_stack_head(self.attention_net_WSI, self.classifier, bag, self.training)

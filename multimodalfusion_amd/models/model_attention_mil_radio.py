@@ -7,62 +7,50 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.utils import initialize_weights
-from .model_modules import Attn_Net, Attn_Net_Gated, amil_stack, amil_stack_head
+from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, make_amil_stack
 
 
 class MIL_Attention_fc_radio(nn.Module):
+    """Parameter container: `reduce_dim` (several modalities), `attention_net_radio`, `classifier`."""
+
     def __init__(self, radio_fusion="concat", gate_radio=True, dropout=True, model_size_radio: str = "small",
                  n_classes=4, modalities=["T1", "T2", "T1Gd", "FLAIR"]):
         super().__init__()
-        self.radio_fusion = radio_fusion
-        self.n_classes = n_classes
-        self.size_dict_radio = {"small": [1024, 256, 256], "big": [1024, 512, 384]}
-        self.modalities = modalities
-        size_radio = self.size_dict_radio[model_size_radio]
-        if len(self.modalities) > 1:
-            if self.radio_fusion == "tensor":
-                # unreachable in the reference as well (forward uses an undefined attribute,
+        self.radio_fusion, self.n_classes, self.modalities = radio_fusion, n_classes, modalities
+        self.size_dict_radio = {name: list(dims) for name, dims in AMIL_SIZES.items()}
+        feat, hidden, _ = AMIL_SIZES[model_size_radio]
+        n_mod = len(modalities)
+        if n_mod > 1:                           # created before the stack, as in the reference (:27-32): same RNG order
+            if radio_fusion == "concat":
+                self.reduce_dim = nn.Linear(feat * n_mod, feat)
+            elif radio_fusion == "tensor":
+                # unusable in the reference as well (its forward reads an attribute that is never set,
                 # model_attention_mil_radio.py:84; SURVEY.md Appendix C)
                 raise NotImplementedError("radio_fusion='tensor' is unusable in the reference and not provided")
-            elif self.radio_fusion == "concat":
-                self.reduce_dim = nn.Linear(size_radio[0] * len(self.modalities), size_radio[0])
-        fc_radio = [nn.Linear(size_radio[0], size_radio[1]), nn.ReLU(), nn.Dropout(0.25)]
-        if gate_radio:
-            attention_net_radio = Attn_Net_Gated(L=size_radio[1], D=size_radio[2], dropout=dropout, n_classes=1)
-        else:
-            attention_net_radio = Attn_Net(L=size_radio[1], D=size_radio[2], dropout=dropout, n_classes=1)
-        fc_radio.append(attention_net_radio)
-        self.attention_net_radio = nn.Sequential(*fc_radio)
-        self.classifier = nn.Linear(size_radio[1], n_classes)
+        self.attention_net_radio = make_amil_stack(model_size_radio, gated=gate_radio, att_dropout=dropout)
+        self.classifier = nn.Linear(hidden, n_classes)
         initialize_weights(self)
 
     def relocate(self):
-        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        if len(self.modalities) > 1 and self.radio_fusion == "concat":
-            self.reduce_dim = self.reduce_dim.to(device)
-        self.attention_net_radio = self.attention_net_radio.to(device)
-        self.classifier = self.classifier.to(device)
+        self.to(torch.device("cuda" if torch.cuda.is_available() else "cpu"))
 
     def forward(self, h, return_features=False, attention_only=False):
-        pass
+        pass            # abstract in the reference too (:64-65)
 
 
 class MIL_Attention_fc_surv_radio(MIL_Attention_fc_radio):
-    def __init__(self, radio_fusion="concat", gate_radio=True, dropout=True, model_size_radio: str = "small",
-                 n_classes=4, modalities=["T1", "T2", "T1Gd", "FLAIR"]):
-        # the reference forces model_size_radio='small' here (model_attention_mil_radio.py:70)
-        super().__init__(radio_fusion=radio_fusion, gate_radio=gate_radio, model_size_radio="small",
-                         dropout=dropout, n_classes=n_classes, modalities=modalities)
+    def __init__(self, radio_fusion="concat", gate_radio=True, dropout=True, model_size_radio="small", n_classes=4,
+                 modalities=["T1", "T2", "T1Gd", "FLAIR"]):
+        model_size_radio = "small"              # the reference overrides the argument (:70)
+        super().__init__(radio_fusion=radio_fusion, gate_radio=gate_radio, dropout=dropout,
+                         model_size_radio=model_size_radio, n_classes=n_classes, modalities=modalities)
 
     def forward(self, **kwargs):
-        h = [kwargs[m] for m in self.modalities]
-        if len(self.modalities) > 1:
-            h = ops.linear_cat(h, self.reduce_dim.weight, self.reduce_dim.bias)   # cat(axis=1) + reduce_dim
-        else:
-            h = h[0]
-        if kwargs.get("attention_only") or kwargs.get("return_features") or kwargs.get("return_attention"):
-            M, A_raw = amil_stack(self.attention_net_radio, h, self.training)
-            if kwargs.get("attention_only"):
-                return A_raw
-            return M if kwargs.get("return_features") else A_raw
-        return amil_stack_head(self.attention_net_radio, self.classifier, h, self.training)
+        bags = [kwargs[m] for m in self.modalities]
+        # several modalities: cat(axis=1) + reduce_dim without materialising the concatenation (:80-82)
+        x = ops.linear_cat(bags, self.reduce_dim.weight, self.reduce_dim.bias) if len(bags) > 1 else bags[0]
+        flags = [kwargs.get(k) for k in ("attention_only", "return_features", "return_attention")]
+        if any(flags):
+            M, A_raw = amil_stack(self.attention_net_radio, x, self.training)
+            return M if (flags[1] and not flags[0]) else A_raw      # attention_only wins, then features (:91-113)
+        return amil_stack_head(self.attention_net_radio, self.classifier, x, self.training)

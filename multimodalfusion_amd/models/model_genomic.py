@@ -10,30 +10,29 @@ from ..utils.utils import init_max_weights
 from .model_modules import SNN_Block, snn_stack
 
 
+OMIC_SIZES = {"small": (256, 256), "big": (1024, 256)}         # hidden widths of the SNN (model_genomic.py:17)
+
+
 class MaxNet_base(nn.Module):
+    """Parameter container: `fc_omic` (SNN blocks: Linear + SELU + AlphaDropout) and `classifier`."""
+
     def __init__(self, input_dim: int, model_size_omic: str = "small", bag_loss=None, n_classes: int = 4):
         super().__init__()
-        self.n_classes = n_classes
-        self.size_dict_omic = {"small": [256, 256], "big": [1024, 256]}
-        self.bag_loss = bag_loss
-        hidden = self.size_dict_omic[model_size_omic]
-        fc_omic = [SNN_Block(dim1=input_dim, dim2=hidden[0])]
-        for i, _ in enumerate(hidden[1:]):
-            fc_omic.append(SNN_Block(dim1=hidden[i], dim2=hidden[i + 1], dropout=0.25))
-        self.fc_omic = nn.Sequential(*fc_omic)
-        if "nll" in self.bag_loss:
-            self.classifier = nn.Linear(hidden[-1], n_classes)
-        else:
-            self.classifier = nn.Linear(hidden[-1], 1)
+        self.n_classes, self.bag_loss = n_classes, bag_loss
+        self.size_dict_omic = {name: list(w) for name, w in OMIC_SIZES.items()}
+        widths = (input_dim,) + OMIC_SIZES[model_size_omic]
+        # block 0 keeps SNN_Block's default dropout, the others pass 0.25 explicitly, as the reference does (:22-24)
+        self.fc_omic = nn.Sequential(*[SNN_Block(dim1=a, dim2=b) if i == 0 else SNN_Block(dim1=a, dim2=b, dropout=0.25)
+                                       for i, (a, b) in enumerate(zip(widths[:-1], widths[1:]))])
+        # discrete-hazard heads emit n_classes logits, Cox / ranking heads one risk score (:33-36)
+        self.classifier = nn.Linear(widths[-1], n_classes if "nll" in bag_loss else 1)
         init_max_weights(self)
 
     def relocate(self):
-        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.fc_omic = self.fc_omic.to(device)
-        self.classifier = self.classifier.to(device)
+        self.to(torch.device("cuda" if torch.cuda.is_available() else "cpu"))
 
     def forward(self, **kwargs):
-        pass
+        pass            # abstract in the reference too
 
 
 class MaxNet(MaxNet_base):

@@ -220,6 +220,20 @@ class XlinearFusion(nn.Module):
         return out
 
 
+# feature dim, hidden dim, attention dim of the two stack sizes (model_attention_mil_path.py:16, ..._radio.py:20)
+AMIL_SIZES = {"small": (1024, 256, 256), "big": (1024, 512, 384)}
+
+
+def make_amil_stack(size: str, gated: bool, att_dropout: bool) -> nn.Sequential:
+    """The attention stack every head owns: projection (Linear + ReLU + Dropout(0.25)) followed by the gated or plain
+    attention scorer.  Built in the reference's order (projection first, scorer second), so a given torch seed
+    initialises it identically and the state_dict keys are `<name>.0.*` and `<name>.3.*`."""
+    feat, hidden, att = AMIL_SIZES[size]
+    scorer = Attn_Net_Gated if gated else Attn_Net
+    return nn.Sequential(nn.Linear(feat, hidden), nn.ReLU(), nn.Dropout(0.25),
+                         scorer(L=hidden, D=att, dropout=att_dropout, n_classes=1))
+
+
 def amil_stack(seq, x, training):
     """Run Sequential(Linear, ReLU, Dropout(0.25), Attn_Net*) + softmax pooling on the GPU.
     Returns (M [1 x H], A_raw [1 x N]).  Dropout probabilities follow nn.Module.training exactly as
