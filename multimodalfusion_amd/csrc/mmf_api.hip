@@ -109,7 +109,7 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   return w;
 }
 
-static int check_desc(const mmf_amil_desc* d) {
+static int check_desc(const mmf_amil_desc* d, int elem_bytes = 4) {
   if (!d || !d->W1 || !d->b1 || !d->Wa || !d->ba || !d->Wc || !d->bc) return MMF_ERR_ARG;
   if (d->gated && (!d->Wb || !d->bb)) return MMF_ERR_ARG;
   if (d->N < 1) return MMF_ERR_SHAPE;
@@ -119,7 +119,7 @@ static int check_desc(const mmf_amil_desc* d) {
   if (d->N * (int64_t)(d->H > d->D ? d->H : d->D) >= (int64_t)1 << 32) return MMF_ERR_SHAPE;  // 32-bit mask index
   // buffer loads: 32-bit byte offsets, and the "reads as zero" sentinel is 2^31 => every operand < 2 GiB
   const int64_t widest = d->L > 2 * d->D ? d->L : 2 * d->D;
-  if (d->N * widest * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
+  if (d->N * widest * elem_bytes >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
   if (d->p_h < 0.f || d->p_h >= 1.f || d->p_att < 0.f || d->p_att >= 1.f) return MMF_ERR_ARG;
   return MMF_OK;
 }
@@ -184,7 +184,7 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
 }
 
 static int check_desc_bf16(const mmf_amil_desc* d) {
-  if (int e = check_desc(d)) return e;
+  if (int e = check_desc(d, 2)) return e;        // the bag and every [N x *] activation are 2-byte here
   if (d->L % 64 != 0 || d->H % 256 != 0) return MMF_ERR_SHAPE;
   return MMF_OK;
 }
