@@ -41,11 +41,11 @@ class BagsInFlight:
         with torch.cuda.stream(st):
             loss = loss_fn_of_model_call()
             grads = torch.autograd.grad(loss, self.params)
-            flat = torch.cat([g.reshape(-1) for g in grads])
+            pieces = [g.reshape(-1) for g in grads]
             if accumulate and self._used[i]:
-                self.slots[i].add_(flat)
+                self.slots[i].add_(torch.cat(pieces))
             else:
-                self.slots[i].copy_(flat)
+                torch.cat(pieces, out=self.slots[i])          # straight into the slot: one launch
             self._used[i] = True
         return loss
 
