@@ -174,6 +174,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers (FUSED only)
   float* p_l = ds_l + T::BM;
+  MMF_KSTAMP(k0);
   LoadP_K<T::BM, T::NT> la;
   if constexpr (FUSED) {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
@@ -247,7 +248,9 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   lb.init(p.Wa, p.Wb, p.H, p.g.D, col0);
   f32x16 acc[T::MB][T::NB];
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
+  MMF_KSTAMP(k1);
   gemm_mainloop<T>(la, lb, nk, lds, acc);
+  MMF_KSTAMP(k2);
   float4 dm4[T::NB];                         // dM of this lane's columns, loaded once
 #pragma unroll
   for (int nb = 0; nb < T::NB; ++nb) {
@@ -279,6 +282,12 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
       st4(p.du + (size_t)row * p.H + col, du);
     }
   });
+#ifdef MMF_STAMPS
+  MMF_KSTAMP(k3);
+  if ((threadIdx.x & 63) == 0) {     // K-dh: prologue (K-prep), main loop, epilogue, waves
+    atomicAdd(&g_stamps[4], k1 - k0); atomicAdd(&g_stamps[5], k2 - k1); atomicAdd(&g_stamps[6], k3 - k2); atomicAdd(&g_stamps[7], 1ull);
+  }
+#endif
 }
 
 // =============================================================================================
