@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(BwdPrepParams p) {
 // =============================================================================================
 // K-dh : NN GEMM with on-the-fly A operand
 // =============================================================================================
-template <int ROWS, int NT>
+// MODE < 0: gate / dropout switches read at run time; MODE = 2 * gated + dropout: compiled in (wide tiles)
+template <int ROWS, int NT, int MODE = -1>
 struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   using Map = KMap<ROWS, NT>;
   GateBwdCtx g;
@@ -114,7 +115,30 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
       rb4[i] = bld4(rb, voff[i], soff);
     }
   }
+  template <bool GATED, bool DROP, int PART>
+  __device__ inline void store_t(float* lds) const {
+    const int c = d0 + 4 * (tid & 7);
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      if (!Map::valid(tid, i)) continue;
+      int rr = row0 + Map::row(tid, i);
+      uint32_t idx = (uint32_t)rr * (uint32_t)g.D + (uint32_t)c;
+      float dummy;
+      float4 o;
+      o.x = gate_dp_t<GATED, DROP, PART>(g, ra4[i].x, rb4[i].x, wc4.x, dsr[i], idx + 0, thr, dscale, dummy);
+      o.y = gate_dp_t<GATED, DROP, PART>(g, ra4[i].y, rb4[i].y, wc4.y, dsr[i], idx + 1, thr, dscale, dummy);
+      o.z = gate_dp_t<GATED, DROP, PART>(g, ra4[i].z, rb4[i].z, wc4.z, dsr[i], idx + 2, thr, dscale, dummy);
+      o.w = gate_dp_t<GATED, DROP, PART>(g, ra4[i].w, rb4[i].w, wc4.w, dsr[i], idx + 3, thr, dscale, dummy);
+      st4(lds + Map::lds(tid, i), o);
+    }
+  }
   __device__ inline void store(float* lds) const {
+    if constexpr (MODE >= 0) {
+      constexpr bool GATED = (MODE & 2) != 0, DROP = (MODE & 1) != 0;
+      if (GATED && part) store_t<GATED, DROP, 1>(lds);      // one wave-uniform branch per chunk
+      else store_t<GATED, DROP, 0>(lds);
+      return;
+    }
     const int c = d0 + 4 * (tid & 7);
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) {
@@ -165,7 +189,7 @@ struct LoadWab_M {
   }
 };
 
-template <class T, bool FUSED>
+template <class T, bool FUSED, int MODE = -1>
 __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   extern __shared__ __align__(16) float lds[];
   int mt, nt;
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers (FUSED only)
   float* p_l = ds_l + T::BM;
   MMF_KSTAMP(k0);
-  LoadP_K<T::BM, T::NT> la;
+  LoadP_K<T::BM, T::NT, MODE> la;
   if constexpr (FUSED) {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
     // g_i = dM.h_i: every wave takes a contiguous share of the rows; lanes cover float4 pieces of h with 8
@@ -648,8 +672,17 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
   using T = Tile<32 * MB, 256, 1, 8, true, false>;
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
   const int grid = grid_for_tiles(p.mt_count, p.nt_count);
-  if (p.fused_prep)
-    return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid, (3 * T::BM + 16) * 4, st);
+  if (p.fused_prep) {
+    constexpr int extra = (3 * T::BM + 16) * 4;
+    switch ((p.g.gated ? 2 : 0) + (p.g.drop_p > 0.f ? 1 : 0)) {      // gate / dropout switches compiled in
+      case 0: return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true, 0>, p, grid, extra, st);
+      case 1: return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true, 1>, p, grid, extra, st);
+      case 2: return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true, 2>, p, grid, extra, st);
+      // gated + attention dropout: two hashes per element inlined 16 times overflow the 256 VGPRs (48 spilled
+      // inside the loop) -- that combination keeps the run-time switches
+      default: return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid, extra, st);
+    }
+  }
   return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid, st);
 }
 

@@ -29,25 +29,22 @@ __device__ inline float apply_act(float v, int act) {
   }
 }
 
-template <class T>
-__global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
-  extern __shared__ __align__(16) float lds[];
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
-  const int row0 = mt * T::BM, col0 = nt * T::BN;
-
-  LoadK<T::BM, T::NT> la;
-  la.init_segments(p.x, p.nseg, p.kseg, p.ldx, row0, (int)p.M);
-  LoadK<T::BN, T::NT> lb;
-  lb.init(p.w, p.K, col0, p.N);
-
-  f32x16 acc[T::MB][T::NB];
-  MMF_KSTAMP(k0);
-  gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
-  MMF_KSTAMP(k1);
-
+// Epilogue of K-lin.  The activation and the dropout switch are compile-time: with run-time `switch (p.act)` /
+// `if (p.drop_p > 0)` inside the element loop the tile's 448 elements per lane each went through three scalar
+// branches (every taken branch refills the instruction buffer); the kernel dispatches ONCE per workgroup instead.
+// ACT = -1: any activation, decided per element (the rarely used tanh / sigmoid / SELU projections).
+template <class T, int ACT, bool DROP>
+__device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], float* lds, int row0, int col0) {
+#ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
+  {
+    float t = 0.f;
+    for_each_c<T>(acc, [&](int, int, float v) { t += v; });
+    if (t == 1.2345e30f) p.y[0] = t;
+    return;
+  }
+#endif
   const uint32_t thr = drop_threshold(p.drop_p);
-  const float scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+  const float scale = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const uint32_t dkey = p.drop_key + (p.seed_dev ? *p.seed_dev : 0u);   // device-resident part of the seed, if any
   float4 bias4[T::NB];                       // per column strip, loaded once, before any store
 #pragma unroll
@@ -67,12 +64,45 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
       const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        y[e] = apply_act(y[e], p.act);
-        if (p.drop_p > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
+        if constexpr (ACT == ACT_RELU) y[e] = fmaxf(y[e], 0.f);
+        else if constexpr (ACT < 0) y[e] = apply_act(y[e], p.act);
+        if constexpr (DROP) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
+#ifdef MMF_DIAG_NOSTORE       /* diagnostic build: everything but the global stores (results are wrong) */
+      if (y[0] == 1.2345e30f)
+#endif
       st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
     }
   });
+}
+
+template <class T>
+__global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, col0 = nt * T::BN;
+
+  LoadK<T::BM, T::NT> la;
+  la.init_segments(p.x, p.nseg, p.kseg, p.ldx, row0, (int)p.M);
+  LoadK<T::BN, T::NT> lb;
+  lb.init(p.w, p.K, col0, p.N);
+
+  f32x16 acc[T::MB][T::NB];
+  MMF_KSTAMP(k0);
+  gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+  MMF_KSTAMP(k1);
+  const bool drop = p.drop_p > 0.f;
+  if (p.act == ACT_RELU) {
+    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, lds, row0, col0);
+    else linear_epilogue<T, ACT_RELU, false>(p, acc, lds, row0, col0);
+  } else if (p.act == ACT_NONE && !drop) {
+    linear_epilogue<T, ACT_NONE, false>(p, acc, lds, row0, col0);
+  } else if (drop) {
+    linear_epilogue<T, -1, true>(p, acc, lds, row0, col0);
+  } else {
+    linear_epilogue<T, -1, false>(p, acc, lds, row0, col0);
+  }
 #ifdef MMF_STAMPS
   MMF_KSTAMP(k2);
   if ((threadIdx.x & 63) == 0) {

@@ -80,7 +80,26 @@ struct GateBwdCtx {        // what the on-the-fly dP operand needs
 };
 
 // dP[i][k] of one (instance, attention dim): part 0 = d pre-tanh, part 1 = d pre-sigmoid (formulas: mmf_amil_bwd.hip
-// header); a_d_b_d returns the dropped a.b product (dWc needs it).
+// header); a_d_b_d returns the dropped a.b product (dWc needs it).  The gate / dropout / part switches are
+// compile-time: callers sit in the staging path of a GEMM main loop, where a scalar branch per element costs more
+// than the arithmetic it skips (the large-bag kernels are instantiated per (gated, dropout) and pick `part` per chunk).
+template <bool GATED, bool DROP, int PART>
+__device__ inline float gate_dp_t(const GateBwdCtx& g, float av, float bv, float wc, float dsv,
+                                  uint32_t idx, uint32_t thr, float dscale, float& a_d_b_d) {
+  float ma = 1.f, mb = 1.f;
+  if constexpr (DROP) {
+    ma = keep(g.key_a, idx, thr) ? dscale : 0.f;
+    if constexpr (GATED) mb = keep(g.key_b, idx, thr) ? dscale : 0.f;
+  }
+  if constexpr (GATED) {
+    a_d_b_d = (av * ma) * (bv * mb);
+    return PART == 0 ? dsv * wc * (bv * mb) * ma * (1.f - av * av)
+                     : dsv * wc * (av * ma) * mb * bv * (1.f - bv);
+  }
+  a_d_b_d = av * ma;
+  return dsv * wc * ma * (1.f - av * av);
+}
+// the same with run-time switches (small-tile kernels, where the staging path is not the bottleneck)
 __device__ inline float gate_dp(const GateBwdCtx& g, int part, float av, float bv, float wc, float dsv,
                                 uint32_t idx, uint32_t thr, float dscale, float& a_d_b_d) {
   float ma = 1.f, mb = 1.f;

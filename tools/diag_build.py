@@ -6,6 +6,7 @@
 
 noload: the main loops stage nothing after the first chunk (MFMA + LDS reads + epilogue only)
 nomfma: the main loops issue no MFMA (global loads + LDS writes + barriers + epilogue only)
+nostore / noepi: the projection kernel's epilogue without its global stores / no epilogue at all
 """
 import os
 import subprocess
@@ -17,7 +18,8 @@ sys.path.insert(0, ROOT)
 from multimodalfusion_amd import build as B   # noqa: E402
 
 VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
-            "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"]}
+            "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
+            "nostore": ["-DMMF_DIAG_NOSTORE"], "noepi": ["-DMMF_DIAG_NOEPI"]}
 
 
 def main():
