@@ -288,15 +288,15 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   float4 v = zero4();
   float lsum = 0.f;
   int i = rg;
-  for (; i + 3 * RG < nrows; i += 4 * RG) {        // 4 independent row loads in flight (the loop was latency-bound)
-    float4 hv[4];
-    float e[4];
+  for (; i + 7 * RG < nrows; i += 8 * RG) {        // 8 independent row loads in flight (the loop is latency-bound)
+    float4 hv[8];
+    float e[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) hv[u] = ld4(p.h + (size_t)(r0 + i + u * RG) * p.H + 4 * cv);
+    for (int u = 0; u < 8; ++u) hv[u] = ld4(p.h + (size_t)(r0 + i + u * RG) * p.H + 4 * cv);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) e[u] = __expf(s_lds[i + u * RG] - m);
+    for (int u = 0; u < 8; ++u) e[u] = __expf(s_lds[i + u * RG] - m);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       v.x += e[u] * hv[u].x; v.y += e[u] * hv[u].y; v.z += e[u] * hv[u].z; v.w += e[u] * hv[u].w;
       if (cv == 0) lsum += e[u];
     }
@@ -328,10 +328,9 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   }
 }
 
-// single workgroup of 1024 threads: merge the per-group partials.
-// Group weights exp(m_g - m) are computed once into LDS; the column sums then run as H columns x
-// (1024/H) group slices of independent, unrolled loads (the first version's serial dependent
-// loop over groups cost 115 us; this one is a few us).
+// H/32 workgroups of 1024 threads: merge the per-group partials.
+// Group weights exp(m_g - m) are computed once into LDS; the column sums then run as independent, unrolled
+// loads (the first version's serial dependent loop over groups cost 115 us).
 constexpr int MERGE_MAX_GROUPS = 4096;
 __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
   __shared__ float wl[MERGE_MAX_GROUPS];
@@ -364,20 +363,24 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
   l = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) l += red[16 + i];
-  const int SL = 1024 / p.H;             // group slices (H = 256 -> 4, 512 -> 2, 1024 -> 1)
-  const int c = tid % p.H, sl = tid / p.H;
+  // Column sums: workgroup b owns columns 32 b .. 32 b + 31 (a single workgroup reading all n_groups x H partials
+  // was bound by what one CU can pull: 264 KB = 10 us at 256 groups); its 1024 threads are 32 columns x 32 group
+  // slices of independent loads.  m and l above are recomputed by every workgroup (2 floats per group).
+  const int cl = tid & 31, sl = tid >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float acc = 0.f;
   const float* q = p.partials + 2 + c;
 #pragma unroll 8
-  for (int g = sl; g < p.n_groups; g += SL) acc += q[(size_t)g * stride] * wl[g];
+  for (int g = sl; g < p.n_groups; g += 32) acc += q[(size_t)g * stride] * wl[g];
   colred[tid] = acc;
   __syncthreads();
-  if (tid < p.H) {
+  if (tid < 32) {
     float s = 0.f;
-    for (int i = 0; i < SL; ++i) s += colred[i * p.H + tid];
-    p.M[tid] = s / l;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += colred[i * 32 + tid];
+    p.M[c] = s / l;
   }
-  if (tid == 0) { p.stats[0] = m; p.stats[1] = l; }
+  if (blockIdx.x == 0 && tid == 0) { p.stats[0] = m; p.stats[1] = l; }
 }
 
 // =============================================================================================
@@ -478,8 +481,11 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
 }
 
 int pool_groups(int64_t N) {
+  // one 4-wave workgroup per CU: the partial kernel streams h at ~5 TB/s with 256, 512 or 1024 groups alike
+  // (measured), and the merge reads one partial per group
+  static const int cap = getenv("MMF_POOL_GROUPS") ? atoi(getenv("MMF_POOL_GROUPS")) : 256;   // tuning override
   int64_t g = (N + 63) / 64;
-  if (g > 256) g = 256;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   while ((N + g - 1) / g > POOL_MAX_ROWS) g *= 2;
   return (int)g;
@@ -495,8 +501,8 @@ int launch_pool(PoolParams p, hipStream_t st) {
 }
 
 int launch_pool_merge(PoolParams p, hipStream_t st) {
-  if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || 1024 % p.H != 0) return MMF_ERR_SHAPE;
-  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(1), dim3(1024), 0, st, p); }
+  if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || p.H % 32 != 0) return MMF_ERR_SHAPE;
+  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(p.H / 32), dim3(1024), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 

@@ -11,7 +11,7 @@ def main(unit, key):
     s = open(f"multimodalfusion_amd/_build/{unit}-hip-amdgcn-amd-amdhsa-gfx950.s").read()
     for name in [n for n in re.findall(r"^\s*\.amdhsa_kernel (\S+)", s, re.M) if key in n]:
         i = s.index("\n" + name + ":")
-        j = s.find("s_endpgm", i)
+        j = s.find(".Lfunc_end", i)
         lines, labels = [], {}
         for l in s[i:j].split("\n"):
             l = l.split(";")[0].strip()
