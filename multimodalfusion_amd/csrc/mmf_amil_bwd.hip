@@ -15,6 +15,8 @@
 // with a_d = a m_a, b_d = b m_b the dropped activations (m = keep/(1-p); m = 1 in eval).
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "mmf_gemm_core.h"
 #include "mmf_kernels.h"
 
@@ -212,11 +214,22 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
     float4 dm_l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) dm_l[q] = q < PPL ? ld4(p.dM + 4 * (lane + 64 * q)) : zero4();
+    // everything that does not depend on g is requested up front, so its latency hides behind the h stream:
+    // dM.M (dmm), the softmax statistics and this thread's row of A_raw / gA (BM <= NT for the fused tiles)
+    float dmm = 0.f;
+    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
+    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
+    static_assert(T::BM <= T::NT, "one row per thread in K-prep");
+    const int prow = row0 + tid;
+    const bool pok = tid < T::BM && prow < p.N;
+    const float araw = pok ? p.A_raw[prow] : 0.f;
+    const float gav = (pok && p.gA) ? p.gA[prow] : 0.f;
     const int wr0 = wave * RPW, wr1 = wr0 + RPW < T::BM ? wr0 + RPW : T::BM;
-    for (int rb = wr0; rb < wr1; rb += 8) {          // 8 rows at a time
-      float part[8];
+    auto g_rows = [&](auto nrows_c, int rb) {          // NR rows at a time: NR x PPL independent loads per lane
+      constexpr int NR = decltype(nrows_c)::value;
+      float part[NR];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NR; ++u) {
         const int row = row0 + rb + u;
         const int rc = row < p.N ? row : (int)p.N - 1;
         float acc = 0.f;
@@ -229,31 +242,32 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
         part[u] = acc;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) part[u] = wave_sum(part[u]);
-      if (lane < 8 && rb + lane < wr1) {
+      for (int u = 0; u < NR; ++u) part[u] = wave_sum(part[u]);
+      if (lane < NR && rb + lane < wr1) {
         float gv = part[0];
 #pragma unroll
-        for (int u = 1; u < 8; ++u) gv = lane == u ? part[u] : gv;
+        for (int u = 1; u < NR; ++u) gv = lane == u ? part[u] : gv;
         g_l[rb + lane] = gv;
       }
+    };
+    if (PPL == 1) {       // H = 256: a row is one float4 per lane -- 16 rows in flight (the stream is latency-bound)
+      for (int rb = wr0; rb < wr1; rb += 16) g_rows(std::integral_constant<int, 16>{}, rb);
+    } else {
+      for (int rb = wr0; rb < wr1; rb += 8) g_rows(std::integral_constant<int, 8>{}, rb);
     }
-    float dmm = 0.f;
-    for (int c = lane; c < p.H; c += 64) dmm += p.dM[c] * p.Mpool[c];
     dmm = wave_sum(dmm);
     __syncthreads();
-    const float smax = p.stats[0], inv = 1.0f / p.stats[1];
     float dbc = 0.f;
-    for (int rr = tid; rr < T::BM; rr += T::NT) {
-      const int row = row0 + rr;
+    if (tid < T::BM) {
       float pi = 0.f, d = 0.f;
-      if (row < p.N) {
-        pi = __expf(p.A_raw[row] - smax) * inv;
-        d = pi * (g_l[rr] - dmm) + (p.gA ? p.gA[row] : 0.f);
-        if (nt == 0) { p.p_out[row] = pi; p.ds_out[row] = d; }
+      if (pok) {
+        pi = __expf(araw - smax) * inv;
+        d = pi * (g_l[tid] - dmm) + gav;
+        if (nt == 0) { p.p_out[prow] = pi; p.ds_out[prow] = d; }
       }
-      ds_l[rr] = d;
-      p_l[rr] = pi;
-      dbc += d;
+      ds_l[tid] = d;
+      p_l[tid] = pi;
+      dbc = d;
     }
     dbc = wave_sum(dbc);
     float* red = p_l + T::BM;
@@ -275,37 +289,59 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   MMF_KSTAMP(k1);
   gemm_mainloop<T>(la, lb, nk, lds, acc);
   MMF_KSTAMP(k2);
-  float4 dm4[T::NB];                         // dM of this lane's columns, loaded once
+  // ---- epilogue: du = (acc + p dM) relu'(h) scale_h, row-major.  The h values (and p) of block b+1 are requested
+  // before block b is transposed and stored: with the reload inside the block (first version) every one of the
+  // wave's blocks waited a full memory latency for its own h.  A load only waits for the stores issued BEFORE it
+  // (in-order vmcnt), i.e. those of block b-1, which have had a whole block to drain.
+  {
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int rr = lane >> 3, c4 = lane & 7;
+    float* blk = lds + wave * (32 * EPI_STRIDE);
+    constexpr int NBLK = T::MB * T::NB;
+    float4 dm4[T::NB];                         // dM of this lane's columns, loaded once
 #pragma unroll
-  for (int nb = 0; nb < T::NB; ++nb) {
-    const int col = col0 + epilogue_col<T>(nb);
-    dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
+    for (int nb = 0; nb < T::NB; ++nb) {
+      const int col = col0 + epilogue_col<T>(nb);
+      dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
+    }
+    float4 hv[2][4];
+    float pv[2][4];
+    auto fetch = [&](int b, int s) {
+      const int mb = b / T::NB, nb = b % T::NB;
+      const int r = (wm * T::MB + mb) * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = row0 + r + 8 * t;
+        const int rc = row < p.N ? row : (int)p.N - 1;
+        hv[s][t] = col < p.H ? ld4(p.h + (size_t)rc * p.H + col) : zero4();
+        pv[s][t] = FUSED ? p_l[r + 8 * t] : p.p[rc];
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int mb = b / T::NB, nb = b % T::NB, s = b & 1;
+      if (b + 1 < NBLK) fetch(b + 1, s ^ 1);
+      float4 v[4];
+      transpose_block(acc[mb][nb], blk, lane, v);
+      const int r = (wm * T::MB + mb) * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
+      if (col >= p.H) continue;
+      const float4 dm = dm4[nb];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = row0 + r + 8 * t;
+        if (row >= p.N) continue;
+        const float4 h4 = hv[s][t];
+        const float pi = pv[s][t];
+        float4 du;
+        du.x = h4.x > 0.f ? (v[t].x + pi * dm.x) * p.scale_h : 0.f;
+        du.y = h4.y > 0.f ? (v[t].y + pi * dm.y) * p.scale_h : 0.f;
+        du.z = h4.z > 0.f ? (v[t].z + pi * dm.z) * p.scale_h : 0.f;
+        du.w = h4.w > 0.f ? (v[t].w + pi * dm.w) * p.scale_h : 0.f;
+        st4(p.du + (size_t)row * p.H + col, du);
+      }
+    }
   }
-  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
-    const int col = col0 + c;
-    if (col >= p.H) return;
-    float4 hv[4];
-    float pi[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {             // all loads first ...
-      const int row = row0 + r + 8 * t;
-      const int rc = row < p.N ? row : (int)p.N - 1;
-      hv[t] = ld4(p.h + (size_t)rc * p.H + col);
-      pi[t] = FUSED ? p_l[r + 8 * t] : p.p[rc];
-    }
-    const float4 dm = dm4[nb];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {             // ... then the stores
-      const int row = row0 + r + 8 * t;
-      if (row >= p.N) continue;
-      float4 du;
-      du.x = hv[t].x > 0.f ? (v[t].x + pi[t] * dm.x) * p.scale_h : 0.f;
-      du.y = hv[t].y > 0.f ? (v[t].y + pi[t] * dm.y) * p.scale_h : 0.f;
-      du.z = hv[t].z > 0.f ? (v[t].z + pi[t] * dm.z) * p.scale_h : 0.f;
-      du.w = hv[t].w > 0.f ? (v[t].w + pi[t] * dm.w) * p.scale_h : 0.f;
-      st4(p.du + (size_t)row * p.H + col, du);
-    }
-  });
 #ifdef MMF_STAMPS
   MMF_KSTAMP(k3);
   if ((threadIdx.x & 63) == 0) {     // K-dh: prologue (K-prep), main loop, epilogue, waves
