@@ -519,6 +519,31 @@ template <class T, class RowMap>
 __device__ inline void tn_store(const TnProblem& q, int split, int tn, f32x16 (&acc)[T::MB][T::NB], float* lds,
                                 RowMap&& rowmap) {
   float* out = q.out + (size_t)split * q.split_stride;
+  if constexpr (T::PERM) {
+    // permuted fragment layout (mmf_gemm_core.h): block (mb, nb) of a wave holds rows 4 i + mb and columns 2 j + nb
+    // of its 128 x 64 patch.  Transposing both column blocks of a row block gives every lane 8 CONSECUTIVE columns
+    // (2 (4 c4 + e) + nb, e = 0..3) of rows 4 (rr + 8 t) + mb: two float4 stores, 256 contiguous bytes per row.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    const int rr = lane >> 3, c4 = lane & 7;
+    float* blk = lds + wave * (32 * EPI_STRIDE);
+    const int col = tn * T::BN + wn * 64 + 8 * c4;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float4 v0[4], v1[4];
+      transpose_block(acc[mb][0], blk, lane, v0);
+      transpose_block(acc[mb][1], blk, lane, v1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = rowmap(wm * 128 + 4 * (rr + 8 * t) + mb);
+        if (row < 0) continue;
+        float* o = out + (size_t)row * q.ldc + col;
+        if (col < q.Ncols) st4(o, make_float4(v0[t].x, v1[t].x, v0[t].y, v1[t].y));
+        if (col + 4 < q.Ncols) st4(o + 4, make_float4(v0[t].z, v1[t].z, v0[t].w, v1[t].w));
+      }
+    }
+    return;
+  }
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
     const int col = tn * T::BN + c;
     if (col >= q.Ncols) return;

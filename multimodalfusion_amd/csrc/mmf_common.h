@@ -61,6 +61,7 @@ __device__ inline float half_sum(float v) {
 }
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ inline float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 

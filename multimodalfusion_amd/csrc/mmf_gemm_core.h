@@ -51,6 +51,11 @@ struct Tile {
   static constexpr int B_FLOATS = B_KCONTIG ? BN * KSTR : KC * BN;
   static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
   static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+  // PERM (all-m-contiguous 4 x 2-block wave tiles, i.e. the 256x256 TN tile): lane r of a wave feeds the MFMAs of
+  // its 4 row blocks with tile rows 4r .. 4r+3 and those of its 2 column blocks with tile columns 2r, 2r+1, so ONE
+  // ds_read_b128 / ds_read_b64 per k replaces 4 / 2 ds_read_b32 (the TN loop issued 192 LDS reads per 128 MFMAs).
+  // Block mb / nb then holds rows 4 i + mb / columns 2 j + nb of the wave's 128 x 64 patch: see tn_store().
+  static constexpr bool PERM = !A_KCONTIG_ && !B_KCONTIG_ && BM_ / WM_ == 128 && BN_ / WN_ == 64;
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be a multiple of 32x32");
 };
 
@@ -208,9 +213,16 @@ __device__ inline void read_a(const float* __restrict__ As, int g, int lo, int h
     if constexpr (T::A_KCONTIG) {
       float4 t = ld4(As + (arow + mb * 32) * KSTR + 8 * g + 4 * hh);
       f.v[mb - lo][0] = t.x; f.v[mb - lo][1] = t.y; f.v[mb - lo][2] = t.z; f.v[mb - lo][3] = t.w;
-    } else {
+    } else if constexpr (!T::PERM) {
 #pragma unroll
       for (int j = 0; j < G; ++j) f.v[mb - lo][j] = As[(2 * G * g + G * hh + j) * T::BM + arow + mb * 32];
+    }
+  }
+  if constexpr (T::PERM) {        // arow = patch base + 4 r; lo = 0, hi = 4
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const float4 t = ld4(As + (2 * G * g + G * hh + j) * T::BM + arow);
+      f.v[0][j] = t.x; f.v[1][j] = t.y; f.v[2][j] = t.z; f.v[3][j] = t.w;
     }
   }
 }
@@ -222,9 +234,16 @@ __device__ inline void read_b(const float* __restrict__ Bs, int g, int brow, int
     if constexpr (T::B_KCONTIG) {
       float4 t = ld4(Bs + (brow + nb * 32) * KSTR + 8 * g + 4 * hh);
       f.v[nb][0] = t.x; f.v[nb][1] = t.y; f.v[nb][2] = t.z; f.v[nb][3] = t.w;
-    } else {
+    } else if constexpr (!T::PERM) {
 #pragma unroll
       for (int j = 0; j < G; ++j) f.v[nb][j] = Bs[(2 * G * g + G * hh + j) * T::BN + brow + nb * 32];
+    }
+  }
+  if constexpr (T::PERM) {        // brow = patch base + 2 r
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const float2 t = ld2(Bs + (2 * G * g + G * hh + j) * T::BN + brow);
+      f.v[0][j] = t.x; f.v[1][j] = t.y;
     }
   }
 }
@@ -261,8 +280,8 @@ template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                      f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook) {
   const int r = lane & 31, hh = lane >> 5;
-  const int arow = wm * T::MB * 32 + r;
-  const int brow = wn * T::NB * 32 + r;
+  const int arow = wm * T::MB * 32 + (T::PERM ? 4 * r : r);
+  const int brow = wn * T::NB * 32 + (T::PERM ? 2 * r : r);
   constexpr int NG = KC / (2 * T::G);            // fragment groups per chunk: 4 (G = 4) or 8 (G = 2)
   constexpr int NP = T::MB > 4 ? 2 : 1;          // row-block parts
   constexpr int MBH = T::MB > 4 ? (T::MB + 1) / 2 : T::MB;
