@@ -715,6 +715,10 @@ struct LoadPB {
     }
   }
   __device__ inline void store(float* lds) {
+    if (gc.drop_p > 0.f) store_t<true>(lds); else store_t<false>(lds);   // one branch per chunk, none per element
+  }
+  template <bool DROP>
+  __device__ inline void store_t(float* lds) {
     const int c = d0 + 8 * piece(tid);
     const float wc[8] = {wc_lo.x, wc_lo.y, wc_lo.z, wc_lo.w, wc_hi.x, wc_hi.y, wc_hi.z, wc_hi.w};
     float wsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -732,12 +736,12 @@ struct LoadPB {
         float a0, a1, b0 = 0.f, b1 = 0.f, w0, w1;
         unpack2(aw[q], a0, a1);
         if (GATED) unpack2(bw[q], b0, b1);
-        const float oa0 = gate_dp(gc, 0, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
-        const float oa1 = gate_dp(gc, 0, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
+        const float oa0 = gate_dp_t<GATED, DROP, 0>(gc, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
+        const float oa1 = gate_dp_t<GATED, DROP, 0>(gc, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
         pw[q] = pack2(oa0, oa1);
         if (GATED) {
-          const float ob0 = gate_dp(gc, 1, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
-          const float ob1 = gate_dp(gc, 1, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
+          const float ob0 = gate_dp_t<GATED, DROP, 1>(gc, a0, b0, wc[2 * q], dsv, idx + 2 * q, thr, dscale, w0);
+          const float ob1 = gate_dp_t<GATED, DROP, 1>(gc, a1, b1, wc[2 * q + 1], dsv, idx + 2 * q + 1, thr, dscale, w1);
           qw[q] = pack2(ob0, ob1);
         }
         wsum[2 * q] += dsv * w0;

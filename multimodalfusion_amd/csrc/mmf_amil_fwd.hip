@@ -172,6 +172,14 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   f32x16 acc[T::MB][T::NB];
   gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
 
+#ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
+  {
+    float t = 0.f;
+    for_each_c<T>(acc, [&](int, int, float v) { t += v; });
+    if (t == 1.2345e30f) p.s_part[0] = t;
+    return;
+  }
+#endif
   // ---- epilogue (row-major, float4): activations, stores of a / b, per-row partial score ----------------
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
