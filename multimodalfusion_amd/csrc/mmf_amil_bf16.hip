@@ -11,6 +11,7 @@
 //   as it lies in HBM ([instance][column], 16-byte copies) and the MFMA fragments are read with
 //   ds_read_b64_tr_b16, gfx950's transposing LDS read: per 16-lane group it takes a 4-instance x 16-column block
 //   and hands every lane ONE column's 4 instances, i.e. 4 consecutive k of that lane's output row.
+#include <type_traits>
 #include <cstdlib>
 
 #include "mmf_gemm_core.h"
@@ -466,24 +467,28 @@ __global__ __launch_bounds__(512) void amil_fwd_fused_bf16_kernel(FusedFwdParams
     float4 bias4[T::NB];
 #pragma unroll
     for (int nb = 0; nb < T::NB; ++nb) bias4[nb] = ld4(p.b1 + epilogue_col<T>(nb));
-    epilogue_rows<T>(acc, reinterpret_cast<float*>(lds + FF_SCR1), [&](int mb, int nb, int rr, int c, const float4 (&v)[4]) {
-      const float4 b4 = bias4[nb];
+    auto epi = [&](auto drop_c) {              // dropout on / off decided once, not per element
+      constexpr bool DROP = decltype(drop_c)::value;
+      epilogue_rows<T>(acc, reinterpret_cast<float*>(lds + FF_SCR1), [&](int mb, int nb, int rr, int c, const float4 (&v)[4]) {
+        const float4 b4 = bias4[nb];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int R = rr + 8 * t, row = row0 + R;
-        float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
-        const uint32_t idx = (uint32_t)row * 256u + (uint32_t)c;
+        for (int t = 0; t < 4; ++t) {
+          const int R = rr + 8 * t, row = row0 + R;
+          float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
+          const uint32_t idx = (uint32_t)row * 256u + (uint32_t)c;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          y[e] = fmaxf(y[e], 0.f);
-          if (p.p_h > 0.f) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            y[e] = fmaxf(y[e], 0.f);
+            if constexpr (DROP) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
+          }
+          const uint2 pk = pack4(y[0], y[1], y[2], y[3]);
+          if (p.h && row < p.N) *reinterpret_cast<uint2*>(p.h + (size_t)row * 256 + c) = pk;
+          const int cc = c & 63;
+          *reinterpret_cast<uint2*>(lds + FF_HIMG + (c >> 6) * 16384 + R * 128 + 16 * ((cc >> 3) ^ ((R >> 1) & 7)) + (cc & 7) * 2) = pk;
         }
-        const uint2 pk = pack4(y[0], y[1], y[2], y[3]);
-        if (p.h && row < p.N) *reinterpret_cast<uint2*>(p.h + (size_t)row * 256 + c) = pk;
-        const int cc = c & 63;
-        *reinterpret_cast<uint2*>(lds + FF_HIMG + (c >> 6) * 16384 + R * 128 + 16 * ((cc >> 3) ^ ((R >> 1) & 7)) + (cc & 7) * 2) = pk;
-      }
-    });
+      });
+    };
+    if (p.p_h > 0.f) epi(std::true_type{}); else epi(std::false_type{});
   }
   // per-wave constants of the phase-2 epilogue
   const int dj = 32 * wave + r;                            // this lane's dim in the accumulator layout
@@ -573,14 +578,16 @@ __global__ __launch_bounds__(512) void amil_fwd_fused_bf16_kernel(FusedFwdParams
       unpack8(qb[1], *reinterpret_cast<float(*)[8]>(bv + 8));
       const uint32_t idx = (uint32_t)row * 256u + (uint32_t)dq;
       float s = 0.f;
+      if (drop) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float ad = av[e], bd = bv[e];
-        if (drop) {
-          ad = keep(key_a, idx + e, thr_a) ? ad * dscale : 0.f;
-          bd = keep(key_b, idx + e, thr_a) ? bd * dscale : 0.f;
+        for (int e = 0; e < 16; ++e) {
+          const float ad = keep(key_a, idx + e, thr_a) ? av[e] * dscale : 0.f;
+          const float bd = keep(key_b, idx + e, thr_a) ? bv[e] * dscale : 0.f;
+          s += ad * bd * wc[e];
         }
-        s += ad * bd * wc[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += av[e] * bv[e] * wc[e];
       }
       s += __shfl_xor(s, 1, 64);
       if (half == 0) sred[wave * 128 + R] = s;
