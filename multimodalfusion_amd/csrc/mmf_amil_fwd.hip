@@ -230,14 +230,17 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
           }
           const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
           const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
+          if (drop) {       // decided once per row, not per element
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float ad = av[e], bd = bv[e];
-            if (drop) {
-              ad = keep(key_a, idx + e, thr) ? ad * dscale : 0.f;
+            for (int e = 0; e < 4; ++e) {
+              const float ad = keep(key_a, idx + e, thr) ? av[e] * dscale : 0.f;
+              float bd = bv[e];
               if constexpr (GATED) bd = keep(key_b, idx + e, thr) ? bd * dscale : 0.f;
+              rowsum[q] += ad * bd * wc[e];
             }
-            rowsum[q] += ad * bd * wc[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowsum[q] += av[e] * bv[e] * wc[e];
           }
         }
       }
