@@ -289,23 +289,34 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
   constexpr int PER_Q = NS / 4;
   FragA<T> fa[2];
   FragB<T> fb[2];
+#ifdef MMF_DIAG_NOFRAG       /* diagnostic build: fragments read once per chunk only (results are wrong) */
+  read_b<T>(Bs, 0, brow, hh, fb[0]); read_b<T>(Bs, 1, brow, hh, fb[1]);
+  read_a<T>(As, 0, 0, MBH, arow, hh, fa[0]); read_a<T>(As, 1, 0, MBH, arow, hh, fa[1]);
+#else
   read_b<T>(Bs, 0, brow, hh, fb[0]);
   read_a<T>(As, 0, 0, MBH, arow, hh, fa[0]);
+#endif
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int g = s / NP, part = s % NP;
     const int lo = part == 0 ? 0 : MBH, hi = part == 0 ? MBH : T::MB;
+#ifndef MMF_DIAG_NOFRAG
     if (s + 1 < NS) {                            // prefetch the fragments of step s + 1
       const int g1 = (s + 1) / NP, part1 = (s + 1) % NP;
       if (part1 == 0) read_b<T>(Bs, g1, brow, hh, fb[g1 & 1]);
       read_a<T>(As, g1, part1 == 0 ? 0 : MBH, part1 == 0 ? MBH : T::MB, arow, hh, fa[(s + 1) & 1]);
     }
+#endif
     if (s % PER_Q == 0) hook(s / PER_Q);
+#ifndef MMF_DIAG_NOSCHED
     __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef MMF_DIAG_NOMFMA      /* diagnostic builds (tools/diag_build.py): timing only, results are wrong */
     mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
 #endif
+#ifndef MMF_DIAG_NOSCHED
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -369,7 +380,9 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     });
     MMF_STAMP(t2);
     MMF_STAMP(t3);
+#ifndef MMF_DIAG_NOBAR        /* diagnostic build: no barrier between chunks (results are wrong) */
     __syncthreads();
+#endif
     MMF_STAMP(t4);
 #if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
     s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
