@@ -7,6 +7,7 @@
 noload: the main loops stage nothing after the first chunk (MFMA + LDS reads + epilogue only)
 nomfma: the main loops issue no MFMA (global loads + LDS writes + barriers + epilogue only)
 nofrag: noload + the fp32 core reads its LDS fragments once per chunk only (MFMA + barriers + epilogue)
+nogload: the fp32 main loops write stale registers to LDS and issue no global loads after the first chunk
 epi1: row-major epilogues write only their first row block
 nobar / nosched: nofrag + no barrier between chunks / + no sched_barrier around the MFMA blocks
 nostore / noepi: the projection kernel's epilogue without its global stores / no epilogue at all
@@ -24,7 +25,7 @@ VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
             "nostore": ["-DMMF_DIAG_NOSTORE"], "noepi": ["-DMMF_DIAG_NOEPI"],
             "nofrag": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG"],
-            "epi1": ["-DMMF_DIAG_EPI1"],
+            "epi1": ["-DMMF_DIAG_EPI1"], "nogload": ["-DMMF_DIAG_NOGLOAD"],
             "nobar": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR"],
             "nosched": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR", "-DMMF_DIAG_NOSCHED"]}
 
