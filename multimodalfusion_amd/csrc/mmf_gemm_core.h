@@ -373,6 +373,11 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #ifdef MMF_DIAG_NOLOAD
       return;
 #endif
+#ifdef MMF_DIAG_NOGLOAD        /* diagnostic build: LDS writes of stale registers, no global loads (results are wrong) */
+      if (q == 2) la.store(nxt);
+      else if (q == 3) lb.store(nxt + T::A_FLOATS);
+      return;
+#endif
       if (q == 0) la.load(kt + 1);
       else if (q == 1) lb.load(kt + 1);
       else if (q == 2) la.store(nxt);
