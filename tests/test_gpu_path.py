@@ -57,8 +57,13 @@ def run_path_hip(m, monkeypatch=None):
                 A_raw=A_raw.detach().cpu().numpy(), loss=float(loss), M=M, grads=_grads(model))
 
 
-def compare(res, ref, tag=""):
-    """res: HIP fp32 results; ref: fp64 oracle results (same dict layout)."""
+def compare(res, ref, tag="", relu_kink_rows=0):
+    """res: HIP fp32 results; ref: fp64 oracle results (same dict layout).
+
+    relu_kink_rows > 0 (bags of tens of thousands of instances): among N x H pre-activations a few lie within fp32
+    rounding of zero, and relu'(u) then differs between fp32 and the fp64 oracle for that (instance, unit): the
+    unit's row of dW1 is off by that single instance's dh.x (and db1 by its dh).  That many rows of the first
+    layer's gradient may exceed the bar, by at most 1 % of the tensor's max."""
     assert abs(res["loss"] - float(ref["loss"])) <= 1e-5, (tag, res["loss"], float(ref["loss"]))
     np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=1e-4, err_msg=tag)
     np.testing.assert_allclose(res["S"], ref["S"], rtol=0, atol=1e-4, err_msg=tag)
@@ -73,7 +78,13 @@ def compare(res, ref, tag=""):
     for k, g in ref["grads"].items():
         got = res["grads"][k]
         tol = 1e-5 + 1e-4 * max(float(np.abs(g).max()), 1e-30)
-        err = float(np.abs(got - g).max())
+        abs_err = np.abs(got - g)
+        err = float(abs_err.max())
+        if err > tol and relu_kink_rows and k.endswith(".0.weight") or (relu_kink_rows and k.endswith(".0.bias") and err > tol):
+            bad_rows = np.unique(np.nonzero(abs_err.reshape(abs_err.shape[0], -1) > tol)[0])
+            assert len(bad_rows) <= relu_kink_rows and err <= 1e-2 * float(np.abs(g).max()), \
+                f"{tag} grad {k}: {len(bad_rows)} rows beyond {tol:.3e} (max abs err {err:.3e})"
+            continue
         assert err <= tol, f"{tag} grad {k}: max abs err {err:.3e} > {tol:.3e}"
 
 
@@ -117,6 +128,22 @@ def test_path_ragged_sizes(N, gated):
     m = dict(N=N, gated=gated, size="small", K=4, dropout=False, y=N % 4, c=N % 2, alpha=0.15, bias_std=0.05,
              train=False, seed=4000 + N, x_seed=5000 + N, mask_seed=0)
     compare(run_path_hip(m), cases.run_path(m), f"N={N} gated={gated}")
+
+
+@pytest.mark.parametrize("N,gated,dropout,train", [
+    (16421, True, False, True),      # wide tiles (224 / 192 / 128 / 64 rows by bag size), ragged last tile; one mask
+    (16421, False, False, False),    # ungated, eval: K-dh without gate and without dropout
+    (23333, True, True, True),       # gated + attention dropout: the K-dh variant that keeps its run-time switches
+    (19999, False, True, True),      # ungated + attention dropout
+])
+def test_path_ragged_wide_tiles(N, gated, dropout, train, monkeypatch):
+    """The large-bag kernels (wide row tiles with the fused K-prep, the 256x256 split-K tile with its permuted
+    fragment layout, every (gated, dropout) instantiation of K-dh) on bag sizes that end inside a tile, against the
+    live fp64 oracle with the same hash masks."""
+    m = dict(N=N, gated=gated, size="small", K=4, dropout=dropout, y=N % 4, c=N % 2, alpha=0.1, bias_std=0.05,
+             train=train, seed=4200 + N, x_seed=5200 + N, mask_seed=4321)
+    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"N={N} gated={gated} dropout={dropout} train={train}",
+            relu_kink_rows=2)
 
 
 def test_path_big_model_train_masks(monkeypatch):
