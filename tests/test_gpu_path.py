@@ -130,19 +130,20 @@ def test_path_ragged_sizes(N, gated):
     compare(run_path_hip(m), cases.run_path(m), f"N={N} gated={gated}")
 
 
-@pytest.mark.parametrize("N,gated,dropout,train", [
-    (16421, True, False, True),      # wide tiles (224 / 192 / 128 / 64 rows by bag size), ragged last tile; one mask
-    (16421, False, False, False),    # ungated, eval: K-dh without gate and without dropout
-    (23333, True, True, True),       # gated + attention dropout: the K-dh variant that keeps its run-time switches
-    (19999, False, True, True),      # ungated + attention dropout
+@pytest.mark.parametrize("N,gated,dropout,train,size", [
+    (16421, True, False, True, "small"),     # wide tiles (224 / 192 / 128 / 64 rows by bag size), ragged last tile; one mask
+    (16421, False, False, False, "small"),   # ungated, eval: K-dh without gate and without dropout
+    (23333, True, True, True, "small"),      # gated + attention dropout: the K-dh variant that keeps its run-time switches
+    (19999, False, True, True, "small"),     # ungated + attention dropout
+    (17011, True, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile, three gate tiles in K-tn
 ])
-def test_path_ragged_wide_tiles(N, gated, dropout, train, monkeypatch):
+def test_path_ragged_wide_tiles(N, gated, dropout, train, size, monkeypatch):
     """The large-bag kernels (wide row tiles with the fused K-prep, the 256x256 split-K tile with its permuted
     fragment layout, every (gated, dropout) instantiation of K-dh) on bag sizes that end inside a tile, against the
     live fp64 oracle with the same hash masks."""
-    m = dict(N=N, gated=gated, size="small", K=4, dropout=dropout, y=N % 4, c=N % 2, alpha=0.1, bias_std=0.05,
+    m = dict(N=N, gated=gated, size=size, K=4, dropout=dropout, y=N % 4, c=N % 2, alpha=0.1, bias_std=0.05,
              train=train, seed=4200 + N, x_seed=5200 + N, mask_seed=4321)
-    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"N={N} gated={gated} dropout={dropout} train={train}",
+    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"N={N} gated={gated} dropout={dropout} train={train} {size}",
             relu_kink_rows=2)
 
 
