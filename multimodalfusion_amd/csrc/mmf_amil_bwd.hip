@@ -582,7 +582,12 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   extern __shared__ __align__(16) float lds[];
   const int b = blockIdx.x;
   int split, tg;
-  if (p.xcd_map) {       // every tile of one K-split on one XCD (measured: no gain -- the L2s were not the limit)
+  if (p.xcd_map == 2) {  // host-built table: the tiles that share an operand panel sit on one XCD
+    const unsigned e = p.map[b];
+    if (e == 0xFFFFu) return;
+    split = (int)(e >> 5);
+    tg = (int)(e & 31u);
+  } else if (p.xcd_map) {       // every tile of one K-split on one XCD (measured: no gain -- the L2s were not the limit)
     const int xcd = b & 7, idx = b >> 3;
     split = xcd + 8 * (idx / p.total_tiles);
     tg = idx % p.total_tiles;
@@ -831,7 +836,39 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
   if (blocks == 0) return MMF_OK;
   p.total_tiles = blocks;
   static const int env_xcd = getenv("MMF_TN_XCD") ? atoi(getenv("MMF_TN_XCD")) : -1;
-  p.xcd_map = env_xcd >= 0 ? env_xcd : 0;
+  p.xcd_map = env_xcd >= 0 ? env_xcd : 2;      // default: the table (same speed, a third less HBM traffic: PMC 682 -> 477 MB)
+  if (p.xcd_map == 2) {
+    // Pack groups (= the tiles of one problem in one split: they share the A or the B panel) into 8 bins, one per
+    // XCD, largest groups first, each into the least loaded bin; bin x, slot j is workgroup x + 8 j.
+    int bin_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ok = blocks <= 32 && p.splits < 2048;
+    for (int i = 0; i < 512; ++i) p.map[i] = 0xFFFFu;
+    int order[6], np = p.nprob;
+    for (int i = 0; i < np; ++i) order[i] = i;
+    for (int i = 0; i < np; ++i)                       // problems by tile count, descending
+      for (int j = i + 1; j < np; ++j)
+        if (p.prob[order[j]].tiles_m * p.prob[order[j]].tiles_n > p.prob[order[i]].tiles_m * p.prob[order[i]].tiles_n) {
+          const int t = order[i]; order[i] = order[j]; order[j] = t;
+        }
+    for (int oi = 0; oi < np && ok; ++oi) {
+      const TnProblem& q = p.prob[order[oi]];
+      const int n = q.tiles_m * q.tiles_n;
+      if (n == 0) continue;
+      for (int s = 0; s < p.splits && ok; ++s) {
+        int x = 0;
+        for (int k = 1; k < 8; ++k) if (bin_load[k] < bin_load[x]) x = k;
+        if (8 * (bin_load[x] + n) > 512) { ok = false; break; }
+        for (int t = 0; t < n; ++t) p.map[x + 8 * (bin_load[x] + t)] = (uint16_t)((s << 5) | (q.block_begin + t));
+        bin_load[x] += n;
+      }
+    }
+    if (ok) {
+      int mx = 0;
+      for (int k = 0; k < 8; ++k) mx = bin_load[k] > mx ? bin_load[k] : mx;
+      return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, 8 * mx, st);
+    }
+    p.xcd_map = 0;       // too many tiles for the table: plain order
+  }
   const int grid = (p.xcd_map ? 8 * ((p.splits + 7) / 8) : p.splits) * blocks;
   return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
 }

@@ -152,9 +152,13 @@ struct TnParams {
   int64_t K;               // number of instances (rows of A and B)
   int splits, k_per_split; // k_per_split is a multiple of KC
   int total_tiles;         // tiles over all problems (set by launch_tn)
-  int xcd_map;             // 1: all tiles of a split on one XCD
+  int xcd_map;             // 1: all tiles of a split on one XCD; 2: block -> (split, tile) through `map`
   int tile;                // 128 or 256 (set by the caller from tn_tile_dim)
   GateBwdCtx g;
+  // xcd_map == 2: map[b] = split << 5 | tile (0xFFFF: no work).  Blocks b, b+8, b+16, ... run on the same XCD, and
+  // launch_tn() packs the tiles of one (split, problem) -- which read the same A or B panel -- next to each other
+  // there, so a panel is fetched from HBM once per XCD instead of once per tile.
+  uint16_t map[512];
 };
 
 struct NnParams {          // C[M x N] = A[M x K] . B[K x N]   (plain; radio: dh0 = du.W1)
