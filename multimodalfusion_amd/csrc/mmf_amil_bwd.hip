@@ -287,7 +287,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   f32x16 acc[T::MB][T::NB];
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
   MMF_KSTAMP(k1);
-  gemm_mainloop<T>(la, lb, nk, lds, acc);
+  gemm_mainloop<T, decltype(la), decltype(lb), FUSED && MODE >= 0>(la, lb, nk, lds, acc);
   MMF_KSTAMP(k2);
   // ---- epilogue: du = (acc + p dM) relu'(h) scale_h, row-major.  The h values (and p) of block b+1 are requested
   // before block b is transposed and stored: with the reload inside the block (first version) every one of the

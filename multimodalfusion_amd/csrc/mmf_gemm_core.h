@@ -343,7 +343,11 @@ __device__ inline unsigned long long stamp_now() {
 #define MMF_KSTAMP(var)
 #endif
 
-template <class T, class LA, class LB>
+// DEPHASE (8-wave tiles only): the two waves of a SIMD (w and w + 4) run the same code in phase, so they stall in the
+// same unit at the same moment.  With DEPHASE the second group stages half a chunk out of phase: it writes chunk
+// kt+1 (requested one chunk earlier) in quarters 0 / 1 and requests chunk kt+2 in quarters 2 / 3.  Pays only where
+// the staging path holds real VALU work (K-dh builds its A operand there: -3 us); plain copies got slower.
+template <class T, class LA, class LB, bool DEPHASE = false>
 __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
@@ -361,11 +365,16 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
   lb.load(0);
   la.store(lds);
   lb.store(lds + T::A_FLOATS);
+  const bool late = DEPHASE && T::NT == 512 && wave >= 4;
+#ifndef MMF_DIAG_NOLOAD
+  if (late && nk > 1) { la.load(1); lb.load(1); }
+#endif
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     float* cur = lds + (kt & 1) * T::STAGE_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * T::STAGE_FLOATS;
     const bool more = kt + 1 < nk;
+    const bool more2 = kt + 2 < nk;
     MMF_STAMP(t0);
     MMF_STAMP(t1);
     compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int q) {
@@ -378,6 +387,13 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
       else if (q == 3) lb.store(nxt + T::A_FLOATS);
       return;
 #endif
+      if (late) {
+        if (q == 0) la.store(nxt);
+        else if (q == 1) lb.store(nxt + T::A_FLOATS);
+        else if (q == 2) { if (more2) la.load(kt + 2); }
+        else { if (more2) lb.load(kt + 2); }
+        return;
+      }
       if (q == 0) la.load(kt + 1);
       else if (q == 1) lb.load(kt + 1);
       else if (q == 2) la.store(nxt);
