@@ -581,32 +581,39 @@ template <class T>
 __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   extern __shared__ __align__(16) float lds[];
   const int b = blockIdx.x;
-  int split, tg;
+  int split, pi = 0, t;
   if (p.xcd_map == 2) {  // host-built table: the tiles that share an operand panel sit on one XCD
     const unsigned e = p.map[b];
     if (e == 0xFFFFu) return;
     split = (int)(e >> 5);
-    tg = (int)(e & 31u);
-  } else if (p.xcd_map) {       // every tile of one K-split on one XCD (measured: no gain -- the L2s were not the limit)
-    const int xcd = b & 7, idx = b >> 3;
-    split = xcd + 8 * (idx / p.total_tiles);
-    tg = idx % p.total_tiles;
-  } else {
-    split = b / p.total_tiles;
-    tg = b - split * p.total_tiles;
+    const int tg = (int)(e & 31u);
+    for (int i = 1; i < p.nprob; ++i)
+      if (tg >= p.prob[i].tile_begin) pi = i;
+    t = tg - p.prob[pi].tile_begin;
+  } else {               // plain order: problem by problem, split by split
+    for (int i = 1; i < p.nprob; ++i)
+      if (b >= p.prob[i].block_begin) pi = i;
+    const int rel = b - p.prob[pi].block_begin, nt = p.prob[pi].tiles_m * p.prob[pi].tiles_n;
+    split = rel / nt;
+    t = rel - split * nt;
   }
-  if (split >= p.splits) return;
-  int pi = 0;
-  for (int i = 1; i < p.nprob; ++i)
-    if (tg >= p.prob[i].block_begin) pi = i;
   const TnProblem& q = p.prob[pi];
-  const int t = tg - q.block_begin;
+  if (split >= q.splits) return;
   const int tm = t / q.tiles_n, tn = t - tm * q.tiles_n;
-  const int64_t kb64 = (int64_t)split * p.k_per_split;
+  const int64_t kb64 = (int64_t)split * q.k_per_split;
   const int kbase = (int)(kb64 < p.K ? kb64 : p.K);
-  const int kmax = (int)((kb64 + p.k_per_split) < p.K ? (kb64 + p.k_per_split) : p.K);
+  const int kmax = (int)((kb64 + q.k_per_split) < p.K ? (kb64 + q.k_per_split) : p.K);
   const int nk = (kmax - kbase + KC - 1) / KC;
   const bool do_sum = tn == 0 && q.colsum != nullptr;
+#ifdef MMF_STAMPS             /* workgroup life time by tile kind: [0] sum plain, [1] sum gate, [2] count plain, [3] count gate */
+  struct TnLife {
+    unsigned long long t0; int kind;
+    __device__ ~TnLife() {
+      const unsigned long long t1 = stamp_now();
+      if (threadIdx.x == 0) { atomicAdd(&g_stamps[kind], t1 - t0); atomicAdd(&g_stamps[2 + kind], 1ull); }
+    }
+  } life{stamp_now(), q.kind == TN_A_PLAIN ? 0 : 1};
+#endif
 
   LoadM<T::BN, T::NT> lb;
   lb.init(q.B, q.ldb, tn * T::BN, q.Ncols, kbase, kmax);
@@ -818,11 +825,13 @@ int tn_splits(int64_t K, int total_tiles, int tile) {
 template <class T>
 static int launch_tn_t(TnParams p, hipStream_t st) {
   if (p.k_per_split % KC != 0 || p.splits < 1) return MMF_ERR_ARG;
-  int blocks = 0;
+  int tiles = 0, blocks = 0;
   for (int i = 0; i < p.nprob; ++i) {
     TnProblem& q = p.prob[i];
     if (q.Ncols % 4 != 0 || q.ldb % 4 != 0 || q.M % 4 != 0) return MMF_ERR_SHAPE;
     if (q.kind == TN_A_PLAIN && q.lda % 4 != 0) return MMF_ERR_SHAPE;
+    if (q.splits <= 0) { q.splits = p.splits; q.k_per_split = p.k_per_split; }
+    if (q.k_per_split % KC != 0 || q.k_per_split < KC) return MMF_ERR_ARG;
     if (q.kind == TN_A_GATE) {
       const int dt = p.g.gated ? T::BM / 2 : T::BM;      // attention dims per tile (both halves together when gated)
       q.tiles_m = (p.g.D + dt - 1) / dt;
@@ -830,18 +839,20 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
       q.tiles_m = (q.M + T::BM - 1) / T::BM;
     }
     q.tiles_n = (q.Ncols + T::BN - 1) / T::BN;
-    q.block_begin = blocks;          // first global tile index of this problem
-    blocks += q.tiles_m * q.tiles_n;
+    q.tile_begin = tiles;
+    q.block_begin = blocks;
+    tiles += q.tiles_m * q.tiles_n;
+    blocks += q.tiles_m * q.tiles_n * q.splits;
   }
   if (blocks == 0) return MMF_OK;
-  p.total_tiles = blocks;
+  p.total_tiles = tiles;
   static const int env_xcd = getenv("MMF_TN_XCD") ? atoi(getenv("MMF_TN_XCD")) : -1;
-  p.xcd_map = env_xcd >= 0 ? env_xcd : 2;      // default: the table (same speed, a third less HBM traffic: PMC 682 -> 477 MB)
+  p.xcd_map = env_xcd == 0 ? 0 : 2;      // default: the table (same speed, a third less HBM traffic: PMC 682 -> 477 MB)
   if (p.xcd_map == 2) {
     // Pack groups (= the tiles of one problem in one split: they share the A or the B panel) into 8 bins, one per
     // XCD, largest groups first, each into the least loaded bin; bin x, slot j is workgroup x + 8 j.
     int bin_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool ok = blocks <= 32 && p.splits < 2048;
+    bool ok = tiles <= 32;
     for (int i = 0; i < 512; ++i) p.map[i] = 0xFFFFu;
     int order[6], np = p.nprob;
     for (int i = 0; i < np; ++i) order[i] = i;
@@ -854,11 +865,12 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
       const TnProblem& q = p.prob[order[oi]];
       const int n = q.tiles_m * q.tiles_n;
       if (n == 0) continue;
-      for (int s = 0; s < p.splits && ok; ++s) {
+      if (q.splits >= 2048) { ok = false; break; }
+      for (int s = 0; s < q.splits && ok; ++s) {
         int x = 0;
         for (int k = 1; k < 8; ++k) if (bin_load[k] < bin_load[x]) x = k;
         if (8 * (bin_load[x] + n) > 512) { ok = false; break; }
-        for (int t = 0; t < n; ++t) p.map[x + 8 * (bin_load[x] + t)] = (uint16_t)((s << 5) | (q.block_begin + t));
+        for (int t = 0; t < n; ++t) p.map[x + 8 * (bin_load[x] + t)] = (uint16_t)((s << 5) | (q.tile_begin + t));
         bin_load[x] += n;
       }
     }
@@ -869,8 +881,7 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
     }
     p.xcd_map = 0;       // too many tiles for the table: plain order
   }
-  const int grid = (p.xcd_map ? 8 * ((p.splits + 7) / 8) : p.splits) * blocks;
-  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
+  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, blocks, st);
 }
 
 int launch_tn(TnParams p, hipStream_t st) {

@@ -63,6 +63,7 @@ struct AmilWs {
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
   int parts, groups, splits, k_per_split, mstk, tile;
+  int splits_g, k_per_split_g;      // K split of the gate problem (d[Wa;Wb]): more, shorter splits than dW1
   size_t bytes;
 };
 
@@ -86,6 +87,27 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   int64_t kps = (N + splits - 1) / splits;
   w.k_per_split = (int)((kps + KC - 1) / KC * KC);
   if (w.k_per_split < KC) w.k_per_split = KC;
+  // A gate tile builds its A operand (dP from a, b, ds) in the staging path and lives ~8 % longer per K row than a
+  // dW1 tile (stamps: 710 k vs 659 k cycles with equal splits), so the whole launch waited for the gate tiles.  The
+  // workgroups the uniform split leaves over (256 - 6 x 42 = 4) go to the gate problem: 44 splits of 36 chunks beside
+  // 42 of 38 at N = 50k.  Large-bag tile only, at most 12 % more splits.
+  w.splits_g = splits; w.k_per_split_g = w.k_per_split;
+  {
+    static const int env = getenv("MMF_TN_GATE_SPLITS") ? atoi(getenv("MMF_TN_GATE_SPLITS")) : -1;   // tuning override
+    const int t1 = ((H + td - 1) / td) * ((L + td - 1) / td), t2 = tiles - t1;
+    int sg = splits;
+    if (td == 256 && t2 > 0 && splits >= 8) {
+      sg = (256 - t1 * splits) / t2;
+      const int cap = splits + (splits * 12 + 99) / 100;
+      if (sg > cap) sg = cap;
+      if (sg < splits) sg = splits;
+    }
+    if (env > 0) sg = env;
+    const int64_t kg = (N + sg - 1) / sg;
+    int kpg = (int)((kg + KC - 1) / KC * KC);
+    if (kpg < KC) kpg = KC;
+    w.splits_g = sg; w.k_per_split_g = kpg;
+  }
   w.h = take((size_t)N * H);
   w.s_part = take((size_t)w.parts * N);
   w.partials = take((size_t)w.groups * (2 + H));
@@ -101,10 +123,10 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   w.dbc_part = take(PREP_GROUPS);
   w.du = take((size_t)N * H);
   w.slab_w1 = take((size_t)splits * H * L);
-  w.slab_wab = take((size_t)splits * w.mstk * H);
+  w.slab_wab = take((size_t)w.splits_g * w.mstk * H);
   w.cs_b1 = take((size_t)splits * H);
-  w.cs_bab = take((size_t)splits * w.mstk);
-  w.cs_wc = take((size_t)splits * D);
+  w.cs_bab = take((size_t)w.splits_g * w.mstk);
+  w.cs_wc = take((size_t)w.splits_g * D);
   w.bytes = off;
   return w;
 }
@@ -315,6 +337,7 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   q2.B = w.h; q2.ldb = d->H; q2.Ncols = d->H;
   q2.out = w.slab_wab; q2.split_stride = (size_t)w.mstk * d->H; q2.ldc = d->H;
   q2.colsum = w.cs_bab; q2.colsum_stride = w.mstk; q2.colsum2 = w.cs_wc; q2.colsum2_stride = d->D;
+  q2.splits = w.splits_g; q2.k_per_split = w.k_per_split_g;
   if (int e = launch_tn(tp, st)) return e;
 
   ReduceParams rp{};
@@ -323,12 +346,12 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
     rp.seg[n].in = in; rp.seg[n].out = out; rp.seg[n].len = len; rp.seg[n].nsplit = nsplit; rp.seg[n].stride = stride; ++n;
   };
   seg(w.slab_w1, g->dW1, d->H * d->L, w.splits, (size_t)d->H * d->L);
-  seg(w.slab_wab, g->dWa, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
-  if (d->gated) seg(w.slab_wab + (size_t)d->D * d->H, g->dWb, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  seg(w.slab_wab, g->dWa, d->D * d->H, w.splits_g, (size_t)w.mstk * d->H);
+  if (d->gated) seg(w.slab_wab + (size_t)d->D * d->H, g->dWb, d->D * d->H, w.splits_g, (size_t)w.mstk * d->H);
   seg(w.cs_b1, g->db1, d->H, w.splits, d->H);
-  seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
-  if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
-  seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
+  seg(w.cs_bab, g->dba, d->D, w.splits_g, w.mstk);
+  if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits_g, w.mstk);
+  seg(w.cs_wc, g->dWc, d->D, w.splits_g, d->D);
   seg(w.dbc_part, g->dbc, 1, dbc_groups, 1);
   rp.nseg = n;
   return launch_reduce(rp, st);

@@ -143,7 +143,9 @@ struct TnProblem {         // C[M x Ncols] (+)= A^T . B over a slice of the K (i
   float* out; size_t split_stride; int ldc;  // slab s at out + s*split_stride
   float* colsum; size_t colsum_stride;       // per split: column sums of A (bias grads), length M; null = skip
   float* colsum2; size_t colsum2_stride;     // TN_A_GATE only: dWc partials, length D
-  int tiles_m, tiles_n, block_begin;
+  int tiles_m, tiles_n, block_begin;       // block_begin: first workgroup of the problem in the plain block order
+  int tile_begin;                          // first tile index of the problem (over all problems, set by launch_tn)
+  int splits, k_per_split;                 // this problem's K split (0 = TnParams::splits / k_per_split)
 };
 
 struct TnParams {
@@ -152,7 +154,7 @@ struct TnParams {
   int64_t K;               // number of instances (rows of A and B)
   int splits, k_per_split; // k_per_split is a multiple of KC
   int total_tiles;         // tiles over all problems (set by launch_tn)
-  int xcd_map;             // 1: all tiles of a split on one XCD; 2: block -> (split, tile) through `map`
+  int xcd_map;             // 0: plain order (problem, split, tile); 2: block -> (split, tile) through `map`
   int tile;                // 128 or 256 (set by the caller from tn_tile_dim)
   GateBwdCtx g;
   // xcd_map == 2: map[b] = split << 5 | tile (0xFFFF: no work).  Blocks b, b+8, b+16, ... run on the same XCD, and

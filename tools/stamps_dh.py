@@ -18,6 +18,8 @@ for _ in range(10): step()
 torch.cuda.synchronize()
 l.mmf_debug_stamps(1, buf)
 v = [int(t) for t in buf[:8]]; w = max(v[7], 1)
+if v[2] or v[3]:
+    print(f"tn_kernel workgroup life (cycles): plain tiles {v[0]/max(v[2],1):9.0f} ({v[2]//10} per launch)   gate tiles {v[1]/max(v[3],1):9.0f} ({v[3]//10} per launch)")
 print(f"bwd_dh   per wave cycles: prologue {v[4]/w:8.0f}  main loop {v[5]/w:8.0f}  epilogue {v[6]/w:8.0f}  (waves/launch {v[7]//10})")
 l.mmf_debug_stamps(0, buf)
 v = [int(t) for t in buf[:8]]; w = max(v[7], 1)
