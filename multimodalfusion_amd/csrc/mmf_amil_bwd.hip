@@ -422,7 +422,9 @@ struct LoadA_M_Plain {
 //            thread loads a, b (and ds) once and emits both halves -- half the loads and loader registers of a
 //            layout that puts the two halves in different tiles;
 //   ungated: DT = ROWS, columns = d pre-tanh.
-template <int ROWS, int NT, bool GATED>
+// DROP: 0 / 1 = attention dropout off / on, compiled in (the large-bag tile: the kernel is instantiated per value);
+//       -1 = tested per element at run time (small tile)
+template <int ROWS, int NT, bool GATED, int DROP = -1>
 struct LoadA_M_Gate {
   static constexpr int DT = GATED ? ROWS / 2 : ROWS;
   using Map = MMap<DT, NT>;
@@ -483,8 +485,13 @@ struct LoadA_M_Gate {
       float oa[4], ob[4], w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        oa[e] = gate_dp(gg, 0, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
-        ob[e] = GATED ? gate_dp(gg, 1, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
+        if constexpr (DROP >= 0) {
+          oa[e] = gate_dp_t<GATED, DROP != 0, 0>(gg, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
+          ob[e] = GATED ? gate_dp_t<GATED, DROP != 0, 1>(gg, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
+        } else {
+          oa[e] = gate_dp(gg, 0, av[e], GATED ? bv[e] : 0.f, wc[e], dsv, idx + e, thr, dscale, w[e]);
+          ob[e] = GATED ? gate_dp(gg, 1, av[e], bv[e], wc[e], dsv, idx + e, thr, dscale, w[e]) : 0.f;
+        }
       }
       float* dst = lds + Map::krow(tid, i) * ROWS + 4 * Map::c4(tid, i);
       st4(dst, make_float4(oa[0], oa[1], oa[2], oa[3]));
@@ -555,10 +562,10 @@ __device__ inline void tn_store(const TnProblem& q, int split, int tn, f32x16 (&
   });
 }
 
-template <class T, bool GATED>
+template <class T, bool GATED, int DROP>
 __device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q, LoadM<T::BN, T::NT>& lb, int split, int tm,
                                     int tn, int kbase, int kmax, int nk, bool do_sum, float* lds) {
-  using LA = LoadA_M_Gate<T::BM, T::NT, GATED>;
+  using LA = LoadA_M_Gate<T::BM, T::NT, GATED, DROP>;
   constexpr int DT = LA::DT;
   const int D = p.g.D, d0 = tm * DT;
   LA la;
@@ -577,7 +584,7 @@ __device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q, LoadM
   }
 }
 
-template <class T>
+template <class T, int DROP = -1>
 __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   extern __shared__ __align__(16) float lds[];
   const int b = blockIdx.x;
@@ -626,9 +633,9 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
     if (do_sum)
       colsum_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
   } else if (p.g.gated) {
-    tn_gate_tile<T, true>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
+    tn_gate_tile<T, true, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
   } else {
-    tn_gate_tile<T, false>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
+    tn_gate_tile<T, false, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
   }
 }
 
@@ -822,6 +829,16 @@ int tn_splits(int64_t K, int total_tiles, int tile) {
   return splits < 1 ? 1 : splits;
 }
 
+// the large-bag tile is instantiated per attention-dropout state (no per-element test in the gate tiles' staging path)
+template <class T>
+static int launch_tn_grid(const TnParams& p, int grid, hipStream_t st) {
+  if constexpr (T::BM == 256) {
+    if (p.g.drop_p > 0.f) return launch_tiled<T>("tn_kernel", tn_kernel<T, 1>, p, grid, st);
+    return launch_tiled<T>("tn_kernel", tn_kernel<T, 0>, p, grid, st);
+  }
+  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
+}
+
 template <class T>
 static int launch_tn_t(TnParams p, hipStream_t st) {
   if (p.k_per_split % KC != 0 || p.splits < 1) return MMF_ERR_ARG;
@@ -877,11 +894,11 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
     if (ok) {
       int mx = 0;
       for (int k = 0; k < 8; ++k) mx = bin_load[k] > mx ? bin_load[k] : mx;
-      return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, 8 * mx, st);
+      return launch_tn_grid<T>(p, 8 * mx, st);
     }
     p.xcd_map = 0;       // too many tiles for the table: plain order
   }
-  return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, blocks, st);
+  return launch_tn_grid<T>(p, blocks, st);
 }
 
 int launch_tn(TnParams p, hipStream_t st) {
