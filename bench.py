@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md chip table (v_mfma_f32_32x32x2_f32, dense)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); the bf16-storage path is HBM-bound, not MFMA-bound
 HBM_PEAK_GBS = 8000.0
 
 
@@ -428,8 +429,10 @@ def main():
                                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
         tot = flops_per_bag(N)
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         out["whole_step"] = {"tflops": tot / (ms_per_step * 1e-3) / 1e12,
-                             "frac_fp32_mfma_peak": tot / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                             ("frac_bf16_mfma_peak" if bf16 else "frac_fp32_mfma_peak"):
+                                 tot / (ms_per_step * 1e-3) / 1e12 / mfma_peak,
                              "algorithmic_gbs": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9,
                              "frac_hbm_peak": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}
