@@ -415,6 +415,22 @@ struct LoadA_M_Plain {
       if (do_sum) { csum.x += r[i].x; csum.y += r[i].y; csum.z += r[i].z; csum.w += r[i].w; }   // out-of-range reads are 0
     }
   }
+  static constexpr bool kHalves = true;
+  static constexpr int HV = Map::NV / 2;
+  __device__ inline void load_half(int kt, int h) {
+    const unsigned soff = kbase_b + (unsigned)(kt * KC) * ldb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if ((i < HV) == (h == 0)) r[i] = bld4(rs, voff[i], soff);
+  }
+  __device__ inline void store_half(float* lds, int h) {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i) {
+      if ((i < HV) != (h == 0) || !Map::valid(tid, i)) continue;
+      st4(lds + Map::lds(tid, i), r[i]);
+      if (do_sum) { csum.x += r[i].x; csum.y += r[i].y; csum.z += r[i].z; csum.w += r[i].w; }
+    }
+  }
 };
 
 // A[k = instance][m] = dP.  One tile covers DT attention dims d0 .. d0+DT-1:

@@ -22,6 +22,8 @@
 // C/D layout (guide: cdna_hip_programming.md section 3): col = lane & 31,
 // row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
 #pragma once
+#include <type_traits>
+
 #include "mmf_common.h"
 
 namespace mmf {
@@ -155,6 +157,23 @@ struct LoadK {
     for (int i = 0; i < Map::NV; ++i)
       if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
+  // the same in two halves (vector slots [0, NV/2) and [NV/2, NV)): see the 8-slot staging schedule of gemm_mainloop
+  static constexpr bool kHalves = true;
+  static constexpr int HV = Map::NV / 2;
+  __device__ inline void load_half(int kt, int h) {
+    const int k0 = kt * KC;
+    const int sidx = k0 / kseg;
+    const rsrc_t rs = sidx == 0 ? r0 : (sidx == 1 ? r1 : (sidx == 2 ? r2 : r3));
+    const unsigned soff = (unsigned)(k0 - sidx * kseg) * 4u;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if ((i < HV) == (h == 0)) r[i] = bld4(rs, voff[i], soff);
+  }
+  __device__ inline void store_half(float* lds, int h) const {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if ((i < HV) == (h == 0) && Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
+  }
 };
 
 // m-contiguous source S[k][m]; k rows outside [kbase, kmax) and columns >= ncols read as zero
@@ -188,7 +207,25 @@ struct LoadM {
     for (int i = 0; i < Map::NV; ++i)
       if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
+  static constexpr bool kHalves = true;
+  static constexpr int HV = Map::NV / 2;
+  __device__ inline void load_half(int kt, int h) {
+    const unsigned soff = kbase_b + (unsigned)(kt * KC) * ldb;
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if ((i < HV) == (h == 0)) r[i] = bld4(rs, voff[i], soff);
+  }
+  __device__ inline void store_half(float* lds, int h) const {
+#pragma unroll
+    for (int i = 0; i < Map::NV; ++i)
+      if ((i < HV) == (h == 0) && Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
+  }
 };
+
+template <class L, class = void>
+struct has_halves : std::false_type {};
+template <class L>
+struct has_halves<L, std::void_t<decltype(L::kHalves)>> : std::true_type {};
 
 // ---- MFMA over one staged chunk ---------------------------------------------------------------
 // Fragments of k-group q+1 are read from LDS into a second register set BEFORE the 4*MB*NB MFMAs of
@@ -272,10 +309,13 @@ __device__ inline void mfma_part(const FragA<T>& fa, const FragB<T>& fb, int lo,
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[mb - lo][j], fb.v[nb][j], acc[mb][nb], 0, 0, 0);
 }
 
-// `hook(q)` (q = 0..3) runs in front of the MFMA block that opens quarter q of the chunk: the main loop uses it
-// to spread the staging of the NEXT chunk through this chunk's MFMA stream (global loads in quarters 0-1, LDS
-// writes in quarters 2-3) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
+// `hook(s)` (s = 0..NS-1, chunk_steps<T>()) runs in front of the MFMA block of step s: the main loop uses it
+// to spread the staging of the NEXT chunk through this chunk's MFMA stream (global loads in the first half, LDS
+// writes in the second) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
 // address path: ~2000 cycles for a CU's 60 KB) and the LDS writes stalled every wave at once.
+template <class T>
+constexpr int chunk_steps() { return (KC / (2 * T::G)) * (T::MB > 4 ? 2 : 1); }
+
 template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                      f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook) {
@@ -307,7 +347,7 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
       read_a<T>(As, g1, part1 == 0 ? 0 : MBH, part1 == 0 ? MBH : T::MB, arow, hh, fa[(s + 1) & 1]);
     }
 #endif
-    if (s % PER_Q == 0) hook(s / PER_Q);
+    hook(s);
 #ifndef MMF_DIAG_NOSCHED
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -377,11 +417,32 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     const bool more2 = kt + 2 < nk;
     MMF_STAMP(t0);
     MMF_STAMP(t1);
-    compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int q) {
+    compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
       if (!more) return;
 #ifdef MMF_DIAG_NOLOAD
       return;
 #endif
+      constexpr int NS = chunk_steps<T>();
+      if constexpr (NS == 8 && !DEPHASE && has_halves<LA>::value && has_halves<LB>::value) {
+        // plain copies on both sides: one half-operand per step, so that no step issues more than 2-4 VMEM or LDS
+        // instructions per lane (the 4-slot schedule wrote a whole operand, 30 KB per CU, in one burst)
+#ifdef MMF_DIAG_NOGLOAD
+        if (s < 4) return;
+#endif
+        switch (s) {
+          case 0: la.load_half(kt + 1, 0); break;
+          case 1: la.load_half(kt + 1, 1); break;
+          case 2: lb.load_half(kt + 1, 0); break;
+          case 3: lb.load_half(kt + 1, 1); break;
+          case 4: la.store_half(nxt, 0); break;
+          case 5: la.store_half(nxt, 1); break;
+          case 6: lb.store_half(nxt + T::A_FLOATS, 0); break;
+          default: lb.store_half(nxt + T::A_FLOATS, 1); break;
+        }
+        return;
+      }
+      if (s % (NS / 4) != 0) return;
+      const int q = s / (NS / 4);
 #ifdef MMF_DIAG_NOGLOAD        /* diagnostic build: LDS writes of stale registers, no global loads (results are wrong) */
       if (q == 2) la.store(nxt);
       else if (q == 3) lb.store(nxt + T::A_FLOATS);
