@@ -79,6 +79,7 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
 template <class T>
 __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   extern __shared__ __align__(16) float lds[];
+  MMF_KSTAMP(kernel_t0);
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   MMF_KSTAMP(k0);
   gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
   MMF_KSTAMP(k1);
+#ifdef MMF_STAMPS
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], k0 - kernel_t0);     // entry -> loaders initialised
+#endif
   const bool drop = p.drop_p > 0.f;
   if (p.act == ACT_RELU) {
     if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, lds, row0, col0);

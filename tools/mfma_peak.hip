@@ -65,9 +65,55 @@ void run_shape(int nb, int iters, int lds_bytes) {
          nb, NACC, iters, lds_bytes, sum / 20 * 1e3, best * 1e3, ideal_us, ideal_us / (sum / 20 * 1e3) * 100);
   hipFree(out);
 }
+// The GEMM's MFMA order without anything else: 32 chunks x 4 fragment groups x (4 + 3 row blocks) x 4 k-pairs, distinct
+// operand registers per (block, k-pair), optional sched_barrier between the steps and s_barrier per chunk.
+template <bool SCHED, bool BAR>
+__global__ __launch_bounds__(512) void k8g(float* out, int chunks, float a0, float b0) {
+  f32x16 acc[7];
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  float a[7][4], b[4];
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 4; ++j) a[i][j] = a0 + threadIdx.x * 1e-3f + i * 0.1f + j;
+  for (int j = 0; j < 4; ++j) b[j] = b0 + threadIdx.x * 2e-3f + j;
+  for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = (part ? 4 : 0); mb < (part ? 7 : 4); ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][j], b[j], acc[mb], 0, 0, 0);
+        if (SCHED) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (BAR) __syncthreads();
+  }
+  float s = 0.f;
+  for (int i = 0; i < 7; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <bool SCHED, bool BAR>
+void run_gemm_order(int nb, int chunks) {
+  float* out; hipMalloc(&out, nb * 512 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float sum = 0.f;
+  for (int rep = 0; rep < 24; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k8g<SCHED, BAR>), dim3(nb), dim3(512), 0, 0, out, chunks, 0.5f, 0.25f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep >= 4) sum += ms;
+  }
+  printf("GEMM MFMA order: blocks=%d chunks=%d sched_barrier=%d s_barrier=%d : avg %.1f us\n", nb, chunks, (int)SCHED, (int)BAR, sum / 20 * 1e3);
+  hipFree(out);
+}
 int main() {
   run<4>(1, 20000); run<4>(2, 20000); run<1>(1, 40000); run<2>(2, 20000); run<4>(1, 200000);
   run_shape<7>(224, 512, 0); run_shape<7>(256, 512, 0); run_shape<7>(224, 512, 64 * 1024);
   run_shape<4>(224, 896, 0); run_shape<7>(224, 5120, 0);
+  run_gemm_order<false, false>(224, 32); run_gemm_order<true, false>(224, 32);
+  run_gemm_order<false, true>(224, 32); run_gemm_order<true, true>(224, 32);
   return 0;
 }

@@ -23,4 +23,4 @@ if v[2] or v[3]:
 print(f"bwd_dh   per wave cycles: prologue {v[4]/w:8.0f}  main loop {v[5]/w:8.0f}  epilogue {v[6]/w:8.0f}  (waves/launch {v[7]//10})")
 l.mmf_debug_stamps(0, buf)
 v = [int(t) for t in buf[:8]]; w = max(v[7], 1)
-print(f"linear_nt per wave cycles:                    main loop {v[5]/w:8.0f}  epilogue {v[6]/w:8.0f}  (waves/launch {v[7]//10})")
+print(f"linear_nt per wave cycles: entry->loaders {v[4]/w:6.0f}  first stage {v[2]/max(v[3],1):7.0f}  main loop (incl. first stage) {v[5]/w:8.0f}  epilogue {v[6]/w:8.0f}  (waves/launch {v[7]//10})")
