@@ -51,6 +51,16 @@ def test_radio_golden_cases(golden, monkeypatch):
             check_summary(g, f"{tag}/grad/{k}", gr, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,n_mod,train", [(16389, 4, True), (16389, 2, False)])
+def test_radio_large_bags(n, n_mod, train, monkeypatch):
+    """Large multi-modality bags: the projection runs its wide tiles over a K range that is the concatenation of
+    separate modality buffers (segment switch inside the staged loads), the backward its large-bag kernels plus the
+    plain NN GEMM for d(reduce_dim out); ragged last tile; against the live fp64 oracle."""
+    m = dict(n=n, n_mod=n_mod, gated=True, K=4, dropout=False, y=2, c=0, alpha=0.1, bias_std=0.05, train=train,
+             seed=4300 + n_mod, x_seed=5300 + n_mod, mask_seed=99)
+    compare(run_radio_hip(m, monkeypatch), cases.run_radio(m), f"radio n={n} n_mod={n_mod} train={train}", relu_kink_rows=2)
+
+
 @pytest.mark.parametrize("B,K", [(1, 4), (1, 8), (5, 4), (16, 8)])
 def test_surv_head_and_nll(B, K):
     from multimodalfusion_amd import ops
