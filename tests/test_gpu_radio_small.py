@@ -61,6 +61,37 @@ def test_radio_large_bags(n, n_mod, train, monkeypatch):
     compare(run_radio_hip(m, monkeypatch), cases.run_radio(m), f"radio n={n} n_mod={n_mod} train={train}", relu_kink_rows=2)
 
 
+@pytest.mark.parametrize("act", ["none", "relu", "tanh", "sigmoid", "selu"])
+@pytest.mark.parametrize("drop_p", [0.0, 0.25])
+def test_linear_forward_abi_all_activations_large(act, drop_p):
+    """mmf_linear_forward through the C ABI at a size that takes the wide projection tiles, every activation the ABI
+    names (the kernel compiles ReLU / none in and decides the others per element) with and without dropout, ragged
+    row count; against float64 numpy with the oracle's mask."""
+    import ctypes as C
+    from multimodalfusion_amd import _lib
+    l = _lib.lib()
+    M, K, N, seed, site = 17003, 64, 256, 321, 1
+    x = gen.normal(21, (M, K), stream=1)
+    W = gen.normal(22, (N, K), stream=2, std=0.2)
+    b = gen.normal(23, (N,), stream=3, std=0.3)
+    tx, tW, tb = _t(x), _t(W), _t(b)
+    y = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    segs = (C.c_void_p * 1)(tx.data_ptr())
+    code = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}[act]
+    rc = l.mmf_linear_forward(segs, 1, K, M, C.c_void_p(tW.data_ptr()), C.c_void_p(tb.data_ptr()), N, code,
+                              C.c_float(drop_p), seed, site, C.c_void_p(y.data_ptr()),
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    pre = x.astype(np.float64) @ W.astype(np.float64).T + b.astype(np.float64)
+    ref = {"none": lambda v: v, "relu": lambda v: np.maximum(v, 0), "tanh": np.tanh,
+           "sigmoid": lambda v: 1 / (1 + np.exp(-v)),
+           "selu": lambda v: 1.0507009873554805 * np.where(v > 0, v, 1.6732632423543772 * (np.exp(v) - 1))}[act](pre)
+    if drop_p > 0:
+        ref = np.where(gen.keep_mask(seed, site, M, N, drop_p), ref / (1 - drop_p), 0.0)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("B,K", [(1, 4), (1, 8), (5, 4), (16, 8)])
 def test_surv_head_and_nll(B, K):
     from multimodalfusion_amd import ops
