@@ -8,6 +8,7 @@
 //   K-merge M = softmax(A_raw).h, (max, denom)        models/model_attention_mil_path.py:53-56
 #include <cstdlib>
 
+#define MMF_STAMP_FIRST_STAGE      /* stamps builds: this unit owns g_stamps[2..3] for the main loops' first stage */
 #include "mmf_gemm_core.h"
 #include "mmf_kernels.h"
 

@@ -401,7 +401,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
   unsigned long long s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0;
 #endif
-#ifdef MMF_STAMPS
+#if defined(MMF_STAMPS) && defined(MMF_STAMP_FIRST_STAGE)
   const unsigned long long t_enter = stamp_now();
 #endif
   la.load(0);
@@ -413,7 +413,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
   if (late && nk > 1) { la.load(1); lb.load(1); }
 #endif
   __syncthreads();
-#ifdef MMF_STAMPS          /* [2]: first stage (load + LDS write + barrier), [3]: count */
+#if defined(MMF_STAMPS) && defined(MMF_STAMP_FIRST_STAGE)   /* [2]: first stage (load + LDS write + barrier), [3]: count */
   if (lane == 0) { atomicAdd(&g_stamps[2], stamp_now() - t_enter); atomicAdd(&g_stamps[3], 1ull); }
 #endif
   for (int kt = 0; kt < nk; ++kt) {
