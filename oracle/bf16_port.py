@@ -135,3 +135,43 @@ def path_step_bf16(sd, x, y, c, alpha, gated=True, dropout=False, masks=None, rn
     g["classifier.bias"] = bk.grad.numpy()
     return dict(hazards=hazards.detach().numpy(), S=S.detach().numpy(), Y_hat=Y_hat.numpy(),
                 A_raw=A_raw.numpy(), M=M.numpy(), loss=float(loss), grads=g)
+
+
+def _amil_grad_names(prefix, gated, dropout):
+    att = f"{prefix}.3"
+    names = {"dW1": f"{prefix}.0.weight", "db1": f"{prefix}.0.bias"}
+    if gated:
+        names.update({"dWa": f"{att}.attention_a.0.weight", "dba": f"{att}.attention_a.0.bias",
+                      "dWb": f"{att}.attention_b.0.weight", "dbb": f"{att}.attention_b.0.bias",
+                      "dWc": f"{att}.attention_c.weight", "dbc": f"{att}.attention_c.bias"})
+    else:
+        last = 3 if dropout else 2
+        names.update({"dWa": f"{att}.module.0.weight", "dba": f"{att}.module.0.bias",
+                      "dWc": f"{att}.module.{last}.weight", "dbc": f"{att}.module.{last}.bias"})
+    return names
+
+
+def mm_step_bf16(sd_np, radio_xs, path_x, omic_x, y, c, alpha, fusion="concat", gate_path=True, gate_radio=True,
+                 mode="radio_path_omic", rnd=rb):
+    """The multimodal head (models/model_mm_attention_mil.py:128-200, eval mode) with the PATHOLOGY branch in bf16
+    storage -- BASELINE config 5: the path bag and its saved activations are rounded where the bf16 kernels round them
+    (amil_bf16 above), the radiology stack, the omic SNN, the fusion and the classifier are the fp32 path of the
+    reference (oracle/torch_port.py, float64 here).  Gradients: autograd up to d(M_path), then the hand-derived
+    backward of the rounded branch."""
+    from . import torch_port as tp
+    sd = tp.to_torch(sd_np, torch.float64)
+    T = lambda a: torch.as_tensor(np.asarray(a)).to(torch.float64)
+    M, A_raw_p, saved = amil_bf16(sd_np, "attention_net_WSI", path_x, gate_path, False, None, rnd)
+    Mleaf = M.detach().clone().requires_grad_(True)
+    hz, S, Yh, A_raw, MM = tp.mm_forward(sd, [T(x) for x in radio_xs], None, T(omic_x), fusion=fusion,
+                                         gate_path=gate_path, gate_radio=gate_radio, dropout=False, mode=mode,
+                                         path_override=(Mleaf, A_raw_p))
+    loss = tp.nll_loss(hz, S, torch.tensor([int(y)]), torch.tensor([float(c)]), alpha=alpha)
+    names = [k for k in sd if not k.startswith("attention_net_WSI.")]
+    gs = torch.autograd.grad(loss, [sd[k] for k in names] + [Mleaf], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(sd[k])).numpy() for k, g in zip(names, gs[:-1])}
+    pg = amil_bf16_backward(saved, gs[-1])
+    for k, name in _amil_grad_names("attention_net_WSI", gate_path, False).items():
+        grads[name] = pg[k].reshape(np.asarray(sd_np[name]).shape).numpy()
+    return dict(hazards=hz.detach().numpy(), S=S.detach().numpy(), Y_hat=Yh.numpy(), loss=float(loss.detach()),
+                A_raw={k: v.detach().numpy() for k, v in A_raw.items()}, grads=grads)

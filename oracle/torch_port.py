@@ -160,11 +160,13 @@ def xfusion(sd, prefix, v_list, masks=None):
 
 
 def mm_forward(sd, radio_xs, path_x, omic_x, fusion="concat", gate_path=True, gate_radio=True,
-               dropout=False, mode="radio_path_omic", masks=None):
+               dropout=False, mode="radio_path_omic", masks=None, path_override=None):
     """models/model_mm_attention_mil.py:128-200 (radio_fusion='concat').
 
     omic_x is 1-D [G] (the forward does X.unsqueeze(0), :165).  masks is a dict of
     dicts: {'radio':{h,a,b}, 'path':{h,a,b}, 'omic_keeps':[k0,k1], 'mm':{...}, 'cls': mask}.
+    path_override = (M_path, A_raw_path): the pathology branch computed elsewhere (oracle/bf16_port.py supplies the
+    bf16-rounded branch as a leaf so that its hand-derived backward can take over from d(M_path)).
     """
     masks = masks or {}
     A_raw = {}
@@ -177,7 +179,10 @@ def mm_forward(sd, radio_xs, path_x, omic_x, fusion="concat", gate_path=True, ga
         A_raw["radiology"] = A
         vs["radio"] = M_radio
     if "path" in mode:
-        M_path, A = amil_pool(sd, "attention_net_WSI", path_x, gate_path, dropout, masks.get("path"))
+        if path_override is not None:
+            M_path, A = path_override
+        else:
+            M_path, A = amil_pool(sd, "attention_net_WSI", path_x, gate_path, dropout, masks.get("path"))
         A_raw["pathology"] = A
         vs["path"] = M_path
     if "omic" in mode:

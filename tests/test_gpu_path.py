@@ -57,13 +57,20 @@ def run_path_hip(m, monkeypatch=None):
                 A_raw=A_raw.detach().cpu().numpy(), loss=float(loss), M=M, grads=_grads(model))
 
 
-def compare(res, ref, tag="", relu_kink_rows=0):
+def relu_kink_units(sd, x, prefix="attention_net_WSI", thr=4e-6):
+    """Hidden units of the first layer that have a pre-activation within fp32 rounding of zero for some instance of the
+    bag (fp64 on the CPU): there relu'(u) legitimately differs between an fp32 and an fp64 evaluation, so that unit's
+    row of dW1 (and entry of db1) may be off by that one instance's dh.x.  Among the N x H = 4..12 million
+    pre-activations of a 16k-50k bag (std ~1.3) a handful lie that close to zero."""
+    u = np.asarray(x, np.float64) @ np.asarray(sd[prefix + ".0.weight"], np.float64).T + np.asarray(sd[prefix + ".0.bias"], np.float64)
+    return set(np.nonzero((np.abs(u) < thr).any(axis=0))[0].tolist())
+
+
+def compare(res, ref, tag="", kink_units=None, kink_prefix="attention_net_WSI"):
     """res: HIP fp32 results; ref: fp64 oracle results (same dict layout).
 
-    relu_kink_rows > 0 (bags of tens of thousands of instances): among N x H pre-activations a few lie within fp32
-    rounding of zero, and relu'(u) then differs between fp32 and the fp64 oracle for that (instance, unit): the
-    unit's row of dW1 is off by that single instance's dh.x (and db1 by its dh).  That many rows of the first
-    layer's gradient may exceed the bar, by at most 1 % of the tensor's max."""
+    kink_units (see relu_kink_units): rows of the first layer's gradient that may exceed the bar, by at most 1 % of
+    the tensor's max, because the oracle itself shows a pre-activation of that unit sitting on the ReLU kink."""
     assert abs(res["loss"] - float(ref["loss"])) <= 1e-5, (tag, res["loss"], float(ref["loss"]))
     np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=1e-4, err_msg=tag)
     np.testing.assert_allclose(res["S"], ref["S"], rtol=0, atol=1e-4, err_msg=tag)
@@ -80,10 +87,10 @@ def compare(res, ref, tag="", relu_kink_rows=0):
         tol = 1e-5 + 1e-4 * max(float(np.abs(g).max()), 1e-30)
         abs_err = np.abs(got - g)
         err = float(abs_err.max())
-        if err > tol and relu_kink_rows and k.endswith(".0.weight") or (relu_kink_rows and k.endswith(".0.bias") and err > tol):
-            bad_rows = np.unique(np.nonzero(abs_err.reshape(abs_err.shape[0], -1) > tol)[0])
-            assert len(bad_rows) <= relu_kink_rows and err <= 1e-2 * float(np.abs(g).max()), \
-                f"{tag} grad {k}: {len(bad_rows)} rows beyond {tol:.3e} (max abs err {err:.3e})"
+        if err > tol and kink_units and k in (kink_prefix + ".0.weight", kink_prefix + ".0.bias"):
+            bad_rows = set(np.unique(np.nonzero(abs_err.reshape(abs_err.shape[0], -1) > tol)[0]).tolist())
+            assert bad_rows <= kink_units and err <= 1e-2 * float(np.abs(g).max()), \
+                f"{tag} grad {k}: rows {sorted(bad_rows)} beyond {tol:.3e} (max abs err {err:.3e}); kink units {sorted(kink_units)}"
             continue
         assert err <= tol, f"{tag} grad {k}: max abs err {err:.3e} > {tol:.3e}"
 
@@ -143,8 +150,9 @@ def test_path_ragged_wide_tiles(N, gated, dropout, train, size, monkeypatch):
     live fp64 oracle with the same hash masks."""
     m = dict(N=N, gated=gated, size=size, K=4, dropout=dropout, y=N % 4, c=N % 2, alpha=0.1, bias_std=0.05,
              train=train, seed=4200 + N, x_seed=5200 + N, mask_seed=4321)
+    sd, x, _ = cases.path_inputs(m)
     compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"N={N} gated={gated} dropout={dropout} train={train} {size}",
-            relu_kink_rows=2)
+            kink_units=relu_kink_units(sd, x))
 
 
 def test_path_big_model_train_masks(monkeypatch):

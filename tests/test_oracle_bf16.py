@@ -47,3 +47,26 @@ def test_bf16_rounding_stays_within_quantisation_of_the_reference(golden):
             # (absolute floor: with N = 1 the score gradient ds is analytically zero and so are dWa/dWb/dWc)
             err, ref = float(np.linalg.norm(q["grads"][k] - ge)), float(np.linalg.norm(ge))
             assert err <= 0.15 * ref + 1e-6, (name, k, err, ref)
+
+
+def test_mm_extension_reproduces_the_autograd_oracle_without_rounding(golden):
+    """oracle/bf16_port.mm_step_bf16 (multimodal head with the hand-derived pathology backward): with rounding off it
+    must equal the autograd oracle -- which the mm fixtures from the imported reference pin (test_oracle_golden.py) --
+    on every multimodal fixture case."""
+    g = golden("mm")
+    n = 0
+    for name, m in g.meta.items():
+        if "path" not in m["mode"]:
+            continue
+        sd, xs, xp, xo = cases.mm_inputs(m)
+        got = bf16_port.mm_step_bf16(sd, xs, xp, xo, m["y"], m["c"], m["alpha"], fusion=m["fusion"],
+                                     gate_path=m["gate_path"], gate_radio=m["gate_radio"], mode=m["mode"], rnd=None)
+        ref = cases.run_mm(m)
+        assert abs(got["loss"] - float(ref["loss"])) <= 1e-10
+        np.testing.assert_allclose(got["hazards"], ref["hazards"], rtol=0, atol=1e-10)
+        for k in ref["A_raw"]:
+            np.testing.assert_allclose(got["A_raw"][k], ref["A_raw"][k], rtol=0, atol=1e-10)
+        for k, gr in ref["grads"].items():
+            np.testing.assert_allclose(got["grads"][k], gr, rtol=1e-8, atol=1e-11, err_msg=f"{name} {k}")
+        n += 1
+    assert n >= 2
