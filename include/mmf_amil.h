@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (fp32, row-major, 16-byte aligned)
- *     unless the comment says "host";  the library allocates nothing and keeps no state;
+ *     unless the comment says "host";  the library allocates nothing and keeps no state (no globals: the optional
+ *     device-resident dropout seed and the optional kernel trace are passed per call);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream), performs no host synchronisation, and is re-entrant / thread-safe (autograd
  *     calls backward from another thread);
@@ -44,6 +45,8 @@ int mmf_abi_version(void);
  *            models/model_modules.py:70-85 (Attn_Net), :87-110 (Attn_Net_Gated),
  *            and the same stack in model_attention_mil_radio.py:88-99 / model_mm_attention_mil.py:146-160.
  * ------------------------------------------------------------------------------------------- */
+struct mmf_trace;
+
 typedef struct mmf_amil_desc {
   int64_t N;          /* instances in the bag */
   int32_t L, H, D;    /* feature dim, hidden dim, attention dim: small 1024/256/256, big 1024/512/384 */
@@ -59,6 +62,10 @@ typedef struct mmf_amil_desc {
   float p_h;          /* dropout prob after the ReLU (0.25 in train mode, 0 in eval) */
   float p_att;        /* dropout prob on the tanh / sigmoid branches (0.25 iff dropout=True and training) */
   uint32_t seed;      /* dropout seed of this call; masks are regenerated, never stored */
+  const uint32_t* seed_dev;  /* optional DEVICE word added to `seed` by every kernel of the call (uint32 wrap), or NULL.
+                              * By-value seeds are frozen into a captured hipGraph; a graph whose first node bumps this
+                              * word draws fresh masks on every replay.  Forward and backward must see the same value. */
+  struct mmf_trace* trace;   /* optional kernel trace (mmf_trace_create), or NULL: see "Kernel trace" below */
 } mmf_amil_desc;
 
 typedef struct mmf_amil_grads {
@@ -118,7 +125,8 @@ int mmf_amil_bf16_infer(const mmf_amil_desc* desc, const uint16_t* x, void* work
  * ------------------------------------------------------------------------------------------- */
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
                        const float* W, const float* bias, int32_t N, int32_t act,
-                       float drop_p, uint32_t drop_seed, uint32_t drop_site, float* y, void* stream);
+                       float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* seed_dev,
+                       float* y, void* stream);
 
 size_t mmf_linear_backward_workspace_bytes(int64_t M, int32_t N, int32_t K);
 /* dy [M x N] (gradient w.r.t. the pre-activation output) -> dW [N x K], db [N] (may be NULL),
@@ -137,7 +145,9 @@ int mmf_surv_head_backward(const float* g_hazards, const float* g_S, const float
                            const float* Wk, int32_t B, int32_t F, int32_t K,
                            float* dfeat, float* dWk, float* dbk, void* stream);
 
-/* nll_surv loss (utils/loss_utils.py:22-39): loss [1], and its gradients g_hazards, g_S [B x K]. */
+/* nll_surv loss (utils/loss_utils.py:22-39): loss [1], and its gradients g_hazards, g_S [B x K].
+ * A label outside [0, K) (the reference's gather raises an index error) poisons the result instead of the memory:
+ * loss = NaN, that sample's gradients = 0; nothing is read or written out of bounds. */
 int mmf_nll_surv(const float* hazards, const float* S, const int64_t* Y, const float* c, int32_t B, int32_t K,
                  float alpha, float eps, float* loss, float* g_hazards, float* g_S, void* stream);
 
@@ -151,34 +161,38 @@ int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_
  *   stacks and gating of XlinearFusion (models/model_modules.py:133-178), and the fusion classifiers
  *   (models/model_mm_attention_mil.py:91,95).
  *   drop_kind: 0 none, 1 nn.Dropout, 2 nn.AlphaDropout; the mask is the keep-hash of (seed, site, element).
+ *   seed_dev (everywhere below): optional device word added to `seed`, or NULL -- see mmf_amil_desc.
  * ------------------------------------------------------------------------------------------- */
 int mmf_dense_forward(const float* x, const float* W, const float* bias, int32_t B, int32_t K, int32_t N,
                       int32_t act, int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
-                      float* y, void* stream);
+                      const uint32_t* seed_dev, float* y, void* stream);
 /* dy, y (the forward OUTPUT) -> dx [B x K] (may be NULL), dW [N x K], db [N] (may be NULL);
  * dpre_scratch: [B x N] floats. */
 int mmf_dense_backward(const float* dy, const float* y, const float* x, const float* W,
                        int32_t B, int32_t K, int32_t N, int32_t act,
-                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev,
                        float* dpre_scratch, float* dx, float* dW, float* db, void* stream);
 /* o = sigmoid(z) * h (n elements) and its backward. */
 int mmf_gate_mul_forward(const float* z, const float* h, float* o, int32_t n, void* stream);
 int mmf_gate_mul_backward(const float* g, const float* z, const float* h, float* dz, float* dh, int32_t n, void* stream);
 /* out[b] = [o0,1] (x) [o1,1] ((x) [o2,1]) followed by Dropout(drop_p); o_t: [B x dim]; m = 2 or 3 (HOST array of ptrs). */
 int mmf_kron_forward(const float* const* o, int32_t m, int32_t dim, int32_t B,
-                     float drop_p, uint32_t seed, uint32_t site, float* out, void* stream);
+                     float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev, float* out, void* stream);
 int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t dim, int32_t B,
-                      float drop_p, uint32_t seed, uint32_t site, float* const* d_o, void* stream);
+                      float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev, float* const* d_o,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-step tail on flat fp32 buffers: the gradient of l1_reg_all + torch.optim.Adam(weight_decay) in one launch.
  *   replaces utils/utils.py:249-257 (l1_reg_all, through autograd) + utils/utils.py:144-146 (Adam) as used by
  *   utils/core_utils.py:216-219,242-247.  l1_coeff = lambda_reg x (micro-batches accumulated since the last step);
  *   step = 1-based optimizer step count.  w, m, v are updated in place.
+ *   l1_mask: NULL = the L1 term covers every element (l1_reg_all); else [n] floats in {0, 1} selecting the elements it
+ *   covers (l1_reg_modules, utils/utils.py:259-268: fc_omic and mm only).
  * mmf_abs_sum: out[0] = sum_i |w_i| (the value of l1_reg_all); partials = 512 floats of scratch.
  * ------------------------------------------------------------------------------------------- */
 int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                     float eps, float weight_decay, float l1_coeff, int32_t step, void* stream);
+                     float eps, float weight_decay, float l1_coeff, const float* l1_mask, int32_t step, void* stream);
 int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream);
 
 /* Fused per-modality gating stage of XlinearFusion (models/model_modules.py:158-165), all m <= 3 modalities in ONE
@@ -197,8 +211,8 @@ typedef struct mmf_xreduce_io {
   float* dv[3];
   float* dWh[3]; float* dbh[3]; float* dWz[3]; float* dbz[3]; float* dWo[3]; float* dbo[3];
 } mmf_xreduce_io;
-int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
-int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream);
+int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage-2 building blocks: the embedding-level fusion models trained on the exported [B x 256] features
@@ -212,10 +226,10 @@ int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, 
 int mmf_batchnorm_forward(const float* x, const float* res, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int32_t B, int32_t F, int32_t training,
                           float eps, float momentum, int32_t act, float drop_p, uint32_t seed, uint32_t site,
-                          float* y, float* save_mean, float* save_invstd, void* stream);
+                          const uint32_t* seed_dev, float* y, float* save_mean, float* save_invstd, void* stream);
 int mmf_batchnorm_backward(const float* dy, const float* y, const float* x, const float* gamma,
                            const float* save_mean, const float* save_invstd, int32_t B, int32_t F, int32_t training,
-                           int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                           int32_t act, float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev,
                            float* dx, float* dres /* or NULL */, float* dgamma, float* dbeta, void* stream);
 /* Highway mix, models/model_modules.py:21-25: y = sigmoid(zg) * relu(zn) + (1 - sigmoid(zg)) * zl, elementwise over n. */
 int mmf_highway_mix_forward(const float* zg, const float* zn, const float* zl, int64_t n, float* y, void* stream);
@@ -234,18 +248,18 @@ int mmf_hazards_forward(const float* logits, int32_t B, int32_t K, float* hazard
 int mmf_hazards_backward(const float* g_hazards, const float* g_S, const float* g_risk /* each may be NULL */,
                          const float* hazards, int32_t B, int32_t K, float* dlogits, void* stream);
 
-/* Graph-replay-safe dropout.  By-value seeds are frozen into a captured hipGraph; with a device word registered here
- * every kernel adds *seed_dev to its dropout keys (effective seed = seed argument + *seed_dev, uint32 wrap), so a
- * graph whose first node increments that word draws fresh masks per replay.  NULL = off (default).  Process-wide. */
-void mmf_set_device_seed(const uint32_t* seed_dev);
-
-/* Per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
- * mmf_profile_dump synchronises, writes "kernel_name launches total_ms" lines into buf, clears the
- * records and returns the number of bytes written (or needed when buf == NULL). */
-void mmf_profile_enable(int on);
-/* Diagnostic builds only (-DMMF_STAMPS): summed s_memtime phase cycles of the GEMM main loop; zeros otherwise. */
-void mmf_debug_stamps(int which, unsigned long long* out8);
-int mmf_profile_dump(char* buf, size_t buf_bytes);
+/* ---------------------------------------------------------------------------------------------
+ * Kernel trace: per-kernel device time of the attention-stack entry points, from HIP events recorded on the LAUNCH
+ * stream around every kernel of a call whose desc->trace is set (bench.py's roofline leg).  A trace is a caller-owned
+ * object (create / destroy); calls that carry the same trace must not run concurrently.  capacity = kernel launches
+ * it can hold; further launches go unrecorded.  mmf_trace_dump synchronises on the recorded events, writes
+ * "kernel_name launches total_ms" lines into buf, clears the records and returns the number of bytes written
+ * (or needed when buf == NULL).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mmf_trace mmf_trace;
+mmf_trace* mmf_trace_create(int32_t capacity);
+void mmf_trace_destroy(mmf_trace* trace);
+int mmf_trace_dump(mmf_trace* trace, char* buf, size_t buf_bytes);
 
 /* Host-side restatement of the device dropout keep-hash (1 = kept).  For tests / mask inspection only. */
 int mmf_dropout_keep_host(uint32_t seed, uint32_t site, uint32_t index, float p);

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -24,6 +24,7 @@ class AmilDesc(C.Structure):
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("Wa", C.c_void_p), ("ba", C.c_void_p),
         ("Wb", C.c_void_p), ("bb", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
         ("p_h", C.c_float), ("p_att", C.c_float), ("seed", C.c_uint32),
+        ("seed_dev", C.c_void_p), ("trace", C.c_void_p),
     ]
 
 
@@ -68,7 +69,7 @@ SYMBOLS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_linear_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                     C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+                                     C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "mmf_linear_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -84,53 +85,81 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_dropout_keep_host": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "mmf_dense_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+                                    C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "mmf_dense_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                     C.c_int32, C.c_float, C.c_uint32, C.c_uint32,
+                                     C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_gate_mul_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mmf_gate_mul_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int32, C.c_void_p]),
     "mmf_kron_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
-                                   C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+                                   C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_kron_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32,
-                                    C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.c_void_p]),
+                                    C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mmf_adam_l1_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
-                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "mmf_abs_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mmf_xreduce_forward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
-    "mmf_xreduce_backward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p]),
+    "mmf_xreduce_forward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mmf_xreduce_backward": (C.c_int, [C.POINTER(XReduceIO), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mmf_batchnorm_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
-                                                         C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4),
+                                                         C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5),
     "mmf_batchnorm_backward": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                                          C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5),
+                                                          C.c_float, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6),
     "mmf_highway_mix_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p]),
     "mmf_highway_mix_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 4),
     "mmf_ranking_loss": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p] * 3),
     "mmf_hazards_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5),
     "mmf_hazards_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mmf_set_device_seed": (None, [C.c_void_p]),
-    "mmf_profile_enable": (None, [C.c_int]),
+    "mmf_trace_create": (C.c_void_p, [C.c_int32]),
+    "mmf_trace_destroy": (None, [C.c_void_p]),
+    "mmf_trace_dump": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+}
+# exported by the diagnostic builds only (tools/diag_build.py, -DMMF_STAMPS)
+DIAG_SYMBOLS = {
     "mmf_debug_stamps": (None, [C.c_int, C.POINTER(C.c_uint64)]),
-    "mmf_profile_dump": (C.c_int, [C.c_char_p, C.c_size_t]),
 }
 
 
-def profile_enable(on: bool):
-    lib().mmf_profile_enable(1 if on else 0)
+class KernelTrace:
+    """Per-kernel device time of the attention-stack calls made inside the `with` block (include/mmf_amil.h
+    "Kernel trace": HIP events on the launch stream).  dump() -> {kernel_name: (launches, total_ms)}."""
 
+    def __init__(self, capacity: int = 4096):
+        self.handle = lib().mmf_trace_create(capacity)
+        if not self.handle:
+            raise MmfError("mmf_trace_create failed")
 
-def profile_dump():
-    """{kernel_name: (launches, total_ms)} since the last dump (HIP events on the launch stream)."""
-    l = lib()
-    buf = C.create_string_buffer(1 << 16)     # one call: the dump clears the records
-    l.mmf_profile_dump(buf, 1 << 16)
-    out = {}
-    for line in buf.value.decode().splitlines():
-        name, cnt, ms = line.split()
-        out[name] = (int(cnt), float(ms))
-    return out
+    def __enter__(self):
+        from . import ops
+        self._prev = ops.set_trace(self.handle)
+        return self
+
+    def __exit__(self, *a):
+        from . import ops
+        ops.set_trace(self._prev)
+
+    def dump(self):
+        l = lib()
+        buf = C.create_string_buffer(1 << 16)     # one call: the dump clears the records
+        l.mmf_trace_dump(self.handle, buf, 1 << 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().mmf_trace_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 _lib = None
 
@@ -153,6 +182,11 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DIAG_SYMBOLS.items():
+            if hasattr(l, name):
+                fn = getattr(l, name)
+                fn.restype = res
+                fn.argtypes = args
         v = l.mmf_abi_version()
         if v != ABI_VERSION:
             raise MmfError(f"libmmf_amil.so ABI version {v}, binding expects {ABI_VERSION}: rebuild")

@@ -1,12 +1,14 @@
 // C ABI (include/mmf_amil.h): argument checks, workspace carving, kernel sequencing.
 // No allocation, no host synchronisation, no global mutable state except the (mutex-guarded)
-// "dynamic LDS attribute already set" set.
+// "dynamic LDS attribute already set" set.  The device-resident dropout seed and the kernel trace are per-call
+// arguments; the trace of the call in progress is held in a thread_local for the launchers (ProfScope).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -32,26 +34,45 @@ int set_dyn_lds(const void* kern, int bytes) {
   return MMF_OK;
 }
 
-// optional device-resident dropout seed (mmf_set_device_seed): every launch folds it into its keys
-static const uint32_t* g_seed_dev = nullptr;
+}  // namespace mmf
 
-struct ProfRec { const char* name; hipEvent_t a, b; };
-static std::mutex g_prof_mu;
-static std::vector<ProfRec> g_prof;
-static bool g_prof_on = false;
+// Caller-owned kernel trace (include/mmf_amil.h "Kernel trace"): HIP event pairs recorded on the launch stream.
+struct mmf_trace {
+  struct Rec { const char* name; hipEvent_t a, b; };
+  std::mutex mu;
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;      // events are reused across dumps
+  int cap = 0;
+};
+
+namespace mmf {
+
+static thread_local mmf_trace* tls_trace = nullptr;
+struct TraceScope {                  // the ABI entry that carries a trace makes it current for its launches
+  mmf_trace* prev;
+  explicit TraceScope(mmf_trace* t) : prev(tls_trace) { tls_trace = t; }
+  ~TraceScope() { tls_trace = prev; }
+};
 
 void prof_begin(const char* name, hipStream_t st) {
-  if (!g_prof_on) return;
-  std::lock_guard<std::mutex> lock(g_prof_mu);
-  ProfRec r{name, nullptr, nullptr};
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  mmf_trace* t = tls_trace;
+  if (!t) return;
+  std::lock_guard<std::mutex> lock(t->mu);
+  if ((int)t->recs.size() >= t->cap) return;
+  auto take = [&](hipEvent_t& e) {
+    if (!t->pool.empty()) { e = t->pool.back(); t->pool.pop_back(); return true; }
+    return hipEventCreate(&e) == hipSuccess;
+  };
+  mmf_trace::Rec r{name, nullptr, nullptr};
+  if (!take(r.a) || !take(r.b)) return;
   hipEventRecord(r.a, st);
-  g_prof.push_back(r);
+  t->recs.push_back(r);
 }
 void prof_end(hipStream_t st) {
-  if (!g_prof_on) return;
-  std::lock_guard<std::mutex> lock(g_prof_mu);
-  if (!g_prof.empty()) hipEventRecord(g_prof.back().b, st);
+  mmf_trace* t = tls_trace;
+  if (!t) return;
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (!t->recs.empty()) hipEventRecord(t->recs.back().b, st);
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -217,7 +238,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 5; }
+int mmf_abi_version(void) { return 6; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -245,19 +266,21 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  const uint32_t* const seed_dev = d->seed_dev;
 
   LinearParams lp{};
   lp.x[0] = x; lp.nseg = 1; lp.kseg = d->L; lp.ldx = d->L;
   lp.w = d->W1; lp.bias = d->b1; lp.y = w.h;
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
-  lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = g_seed_dev;
+  lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
   gp.h = w.h; gp.Wa = d->Wa; gp.ba = d->ba; gp.Wb = d->Wb; gp.bb = d->bb; gp.Wc = d->Wc;
   gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
   gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
-  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = g_seed_dev;
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = seed_dev;
   if (int e = launch_gate_fwd(gp, st)) return e;
 
   PoolParams pp{};
@@ -293,10 +316,12 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  const uint32_t* const seed_dev = d->seed_dev;
 
   GateBwdCtx gc{};
   gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
-  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = g_seed_dev;
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = seed_dev;
 
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
@@ -370,6 +395,8 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  const uint32_t* const seed_dev = d->seed_dev;
 
   CvtParams cp{};
   cp.nseg = 0;
@@ -395,7 +422,7 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     fp.N = d->N; fp.L = d->L; fp.D = d->D;
     fp.p_h = d->p_h; fp.p_att = d->p_att;
     fp.key_h = drop_key(d->seed, 0); fp.key_a = drop_key(d->seed, 1); fp.key_b = drop_key(d->seed, 2);
-    fp.seed_dev = g_seed_dev;
+    fp.seed_dev = seed_dev;
     if (int e = launch_fused_fwd_bf16(fp, d->gated, st)) return e;
     PoolParams pm{};
     pm.N = d->N; pm.H = d->H; pm.partials = w.partials; pm.M = M; pm.stats = w.stats;
@@ -406,7 +433,7 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   LinearBfParams lp{};
   lp.x = x; lp.w = w.w1; lp.bias = d->b1; lp.y = w.h;
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
-  lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = g_seed_dev;
+  lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   if (int e = launch_linear_bf16(lp, st)) return e;
 
   GateBfParams gp{};
@@ -414,7 +441,7 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   gp.ba = d->ba; gp.bb = d->bb; gp.Wc = d->Wc;
   gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
   gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
-  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = g_seed_dev;
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = seed_dev;
   if (int e = launch_gate_bf16(gp, st)) return e;
 
   PoolBfParams pb{};
@@ -452,10 +479,12 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* work
   AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  const uint32_t* const seed_dev = d->seed_dev;
 
   GateBwdBf gc{};
   gc.a = w.a; gc.b = w.b; gc.ds = w.ds; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
-  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = g_seed_dev;
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = seed_dev;
 
   DhBfParams dp{};
   dp.g = gc; dp.WabT = w.wabT; dp.dM = dM; dp.h = w.h; dp.du = w.du;
@@ -498,7 +527,8 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* work
 
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
                        const float* W, const float* bias, int32_t N, int32_t act,
-                       float drop_p, uint32_t drop_seed, uint32_t drop_site, float* y, void* stream) {
+                       float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* seed_dev,
+                       float* y, void* stream) {
   if (!x_segs || nseg < 1 || nseg > 4 || !W || !y) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
   if (M * (int64_t)kseg * 4 >= (int64_t)1 << 31 || (int64_t)N * nseg * kseg * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
@@ -511,7 +541,7 @@ int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, i
   if (!aligned16(W)) return MMF_ERR_ALIGN;
   lp.nseg = nseg; lp.kseg = kseg; lp.ldx = kseg;
   lp.w = W; lp.bias = bias; lp.y = y; lp.M = M; lp.N = N; lp.K = nseg * kseg;
-  lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site); lp.seed_dev = g_seed_dev;
+  lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site); lp.seed_dev = seed_dev;
   return launch_linear(lp, static_cast<hipStream_t>(stream));
 }
 
@@ -600,11 +630,12 @@ int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_
 }
 
 int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                     float eps, float weight_decay, float l1_coeff, int32_t step, void* stream) {
+                     float eps, float weight_decay, float l1_coeff, const float* l1_mask, int32_t step, void* stream) {
   if (!w || !g || !m || !v || n < 1 || step < 1) return MMF_ERR_ARG;
+  if (l1_mask && !aligned16(l1_mask)) return MMF_ERR_ALIGN;
   if (!aligned16(w) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return MMF_ERR_ALIGN;
   AdamParams p{};
-  p.w = w; p.g = g; p.m = m; p.v = v; p.n = n;
+  p.w = w; p.g = g; p.m = m; p.v = v; p.n = n; p.l1_mask = l1_mask;
   p.b1 = beta1; p.b2 = beta2; p.eps = eps; p.wd = weight_decay; p.l1 = l1_coeff;
   // bias corrections in double, as torch computes them on the host
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
@@ -619,31 +650,31 @@ int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* st
   return launch_abs_sum(w, n, partials, out, static_cast<hipStream_t>(stream));
 }
 
-static DropSpec make_drop(int kind, float p, uint32_t seed, uint32_t site) {
+static DropSpec make_drop(int kind, float p, uint32_t seed, uint32_t site, const uint32_t* seed_dev) {
   DropSpec d;
   d.kind = p > 0.f ? kind : 0;
   d.p = p;
   d.key = drop_key(seed, site);
-  d.dev = g_seed_dev;
+  d.dev = seed_dev;
   return d;
 }
 
 int mmf_dense_forward(const float* x, const float* W, const float* bias, int32_t B, int32_t K, int32_t N,
                       int32_t act, int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
-                      float* y, void* stream) {
+                      const uint32_t* seed_dev, float* y, void* stream) {
   if (!x || !W || !y || B < 1 || K < 1 || N < 1) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_kind < 0 || drop_kind > 2 || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
-  DenseParams p{x, W, bias, y, B, K, N, act, make_drop(drop_kind, drop_p, seed, site)};
+  DenseParams p{x, W, bias, y, B, K, N, act, make_drop(drop_kind, drop_p, seed, site, seed_dev)};
   return launch_dense_fwd(p, static_cast<hipStream_t>(stream));
 }
 
 int mmf_dense_backward(const float* dy, const float* y, const float* x, const float* W,
                        int32_t B, int32_t K, int32_t N, int32_t act,
-                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site,
+                       int32_t drop_kind, float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev,
                        float* dpre_scratch, float* dx, float* dW, float* db, void* stream) {
   if (!dy || !y || !x || !W || !dpre_scratch || B < 1 || K < 1 || N < 1) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_kind < 0 || drop_kind > 2) return MMF_ERR_ARG;
-  DenseBwdParams p{dy, y, x, W, dpre_scratch, dx, dW, db, B, K, N, act, make_drop(drop_kind, drop_p, seed, site)};
+  DenseBwdParams p{dy, y, x, W, dpre_scratch, dx, dW, db, B, K, N, act, make_drop(drop_kind, drop_p, seed, site, seed_dev)};
   return launch_dense_bwd(p, static_cast<hipStream_t>(stream));
 }
 
@@ -657,31 +688,35 @@ int mmf_gate_mul_backward(const float* g, const float* z, const float* h, float*
 }
 
 int mmf_kron_forward(const float* const* o, int32_t m, int32_t dim, int32_t B,
-                     float drop_p, uint32_t seed, uint32_t site, float* out, void* stream) {
+                     float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev, float* out, void* stream) {
   if (!o || (m != 2 && m != 3) || dim < 1 || B < 1 || !out) return MMF_ERR_ARG;
   KronParams p{};
   for (int i = 0; i < m; ++i) { if (!o[i]) return MMF_ERR_ARG; p.o[i] = o[i]; }
-  p.out = out; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site);
+  p.out = out; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site, seed_dev);
   return launch_kron_fwd(p, static_cast<hipStream_t>(stream));
 }
 int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t dim, int32_t B,
-                      float drop_p, uint32_t seed, uint32_t site, float* const* d_o, void* stream) {
+                      float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev, float* const* d_o,
+                      void* stream) {
   if (!g || !o || !d_o || (m != 2 && m != 3) || dim < 1 || B < 1) return MMF_ERR_ARG;
   KronParams p{};
   for (int i = 0; i < m; ++i) { if (!o[i] || !d_o[i]) return MMF_ERR_ARG; p.o[i] = o[i]; p.d[i] = d_o[i]; }
-  p.g = g; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site);
+  p.g = g; p.m = m; p.dim = dim; p.B = B; p.drop = make_drop(1, drop_p, seed, site, seed_dev);
   return launch_kron_bwd(p, static_cast<hipStream_t>(stream));
 }
 
 /* diagnostic builds only (-DMMF_STAMPS): which = 0 forward TU, 1 backward TU; out8 = {load, mfma, store, barrier cycles, chunks};
  * which = 2: bf16 TU, writes 32 values (4 kernels x {prologue, main loop, epilogue, -, -, -, -, waves}) */
+#ifdef MMF_STAMPS       /* exported by the diagnostic libraries only (tools/diag_build.py -> multimodalfusion_amd/_diag/) */
 void mmf_debug_stamps(int which, unsigned long long* out8) {
   if (which == 0) debug_stamps_fwd(out8);
   else if (which == 1) debug_stamps_bwd(out8);
   else debug_stamps_bf16(out8);
 }
+#endif
 
-static int xreduce_params(const mmf_xreduce_io* io, float drop_p, uint32_t seed, bool bwd, XReduceParams& p) {
+static int xreduce_params(const mmf_xreduce_io* io, float drop_p, uint32_t seed, const uint32_t* seed_dev, bool bwd,
+                          XReduceParams& p) {
   if (!io || io->m < 1 || io->m > 3 || io->B < 1 || io->dim < 1 || io->sdim < 1) return MMF_ERR_ARG;
   if (drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
   p = XReduceParams{};
@@ -700,39 +735,39 @@ static int xreduce_params(const mmf_xreduce_io* io, float drop_p, uint32_t seed,
       p.dWo[i] = io->dWo[i]; p.dbo[i] = io->dbo[i];
     }
   }
-  p.drop = make_drop(1, drop_p, seed, 0);
+  p.drop = make_drop(1, drop_p, seed, 0, seed_dev);
   return MMF_OK;
 }
-int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream) {
+int mmf_xreduce_forward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
   XReduceParams p;
-  if (int e = xreduce_params(io, drop_p, seed, false, p)) return e;
+  if (int e = xreduce_params(io, drop_p, seed, seed_dev, false, p)) return e;
   return launch_xreduce_fwd(p, static_cast<hipStream_t>(stream));
 }
-int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, void* stream) {
+int mmf_xreduce_backward(const mmf_xreduce_io* io, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
   XReduceParams p;
-  if (int e = xreduce_params(io, drop_p, seed, true, p)) return e;
+  if (int e = xreduce_params(io, drop_p, seed, seed_dev, true, p)) return e;
   return launch_xreduce_bwd(p, static_cast<hipStream_t>(stream));
 }
 
 int mmf_batchnorm_forward(const float* x, const float* res, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int32_t B, int32_t F, int32_t training,
                           float eps, float momentum, int32_t act, float drop_p, uint32_t seed, uint32_t site,
-                          float* y, float* save_mean, float* save_invstd, void* stream) {
+                          const uint32_t* seed_dev, float* y, float* save_mean, float* save_invstd, void* stream) {
   if (!x || !y || !save_mean || !save_invstd || B < 1 || F < 1) return MMF_ERR_ARG;
   if (!training && (!running_mean || !running_var)) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
   BnParams p{x, res, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, B, F, training, act, eps, momentum,
-             make_drop(1, drop_p, seed, site)};
+             make_drop(1, drop_p, seed, site, seed_dev)};
   return launch_bn_fwd(p, static_cast<hipStream_t>(stream));
 }
 int mmf_batchnorm_backward(const float* dy, const float* y, const float* x, const float* gamma,
                            const float* save_mean, const float* save_invstd, int32_t B, int32_t F, int32_t training,
-                           int32_t act, float drop_p, uint32_t seed, uint32_t site,
+                           int32_t act, float drop_p, uint32_t seed, uint32_t site, const uint32_t* seed_dev,
                            float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
   if (!dy || !y || !x || !save_mean || !save_invstd || !dx || B < 1 || F < 1) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
   BnBwdParams p{dy, y, x, gamma, save_mean, save_invstd, dx, dres, dgamma, dbeta, B, F, training, act,
-                make_drop(1, drop_p, seed, site)};
+                make_drop(1, drop_p, seed, site, seed_dev)};
   return launch_bn_bwd(p, static_cast<hipStream_t>(stream));
 }
 int mmf_highway_mix_forward(const float* zg, const float* zn, const float* zl, int64_t n, float* y, void* stream) {
@@ -766,31 +801,36 @@ int mmf_hazards_backward(const float* g_hazards, const float* g_S, const float* 
   return launch_hazard_bwd(p, static_cast<hipStream_t>(stream));
 }
 
-/* Graph-replay-safe dropout: when a device pointer is set, every kernel adds *seed_dev to its dropout keys, so a
- * captured hipGraph whose first node bumps that word draws fresh masks on every replay (by-value seeds are frozen
- * into the captured kernel arguments).  NULL restores the default.  Process-wide; set it before capture. */
-void mmf_set_device_seed(const uint32_t* seed_dev) { g_seed_dev = seed_dev; }
+mmf_trace* mmf_trace_create(int32_t capacity) {
+  if (capacity < 1) return nullptr;
+  mmf_trace* t = new (std::nothrow) mmf_trace();
+  if (t) { t->cap = capacity; t->recs.reserve(capacity); }
+  return t;
+}
 
-void mmf_profile_enable(int on) {
-  std::lock_guard<std::mutex> lock(g_prof_mu);
-  g_prof_on = on != 0;
+void mmf_trace_destroy(mmf_trace* t) {
+  if (!t) return;
+  for (auto& r : t->recs) { if (r.a) hipEventDestroy(r.a); if (r.b) hipEventDestroy(r.b); }
+  for (auto e : t->pool) hipEventDestroy(e);
+  delete t;
 }
 
 // Synchronises on the recorded events, writes "name count total_ms\n" lines, clears the records.
-int mmf_profile_dump(char* buf, size_t buf_bytes) {
-  std::lock_guard<std::mutex> lock(g_prof_mu);
+int mmf_trace_dump(mmf_trace* t, char* buf, size_t buf_bytes) {
+  if (!t) return MMF_ERR_ARG;
+  std::lock_guard<std::mutex> lock(t->mu);
   std::map<std::string, std::pair<int, double>> agg;
-  for (auto& r : g_prof) {
+  for (auto& r : t->recs) {
     float ms = 0.f;
     if (r.a && r.b && hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       auto& e = agg[r.name];
       e.first += 1;
       e.second += ms;
     }
-    if (r.a) hipEventDestroy(r.a);
-    if (r.b) hipEventDestroy(r.b);
+    if (r.a) t->pool.push_back(r.a);
+    if (r.b) t->pool.push_back(r.b);
   }
-  g_prof.clear();
+  t->recs.clear();
   std::string out;
   char line[256];
   for (auto& kv : agg) {

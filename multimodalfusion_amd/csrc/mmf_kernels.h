@@ -197,8 +197,8 @@ int set_dyn_lds(const void* kern, int bytes);
 void debug_stamps_fwd(unsigned long long* out8);
 void debug_stamps_bwd(unsigned long long* out8);
 
-// Optional per-kernel timing with HIP events on the launch stream (off by default; enabled by
-// mmf_profile_enable() for bench.py's roofline leg).  No cost when disabled.
+// Optional per-kernel timing with HIP events on the launch stream: records into the mmf_trace of the ABI call in
+// progress (mmf_amil_desc::trace, thread-local while the call runs); no cost when the call carries none.
 void prof_begin(const char* name, hipStream_t st);
 void prof_end(hipStream_t st);
 struct ProfScope {

@@ -40,6 +40,7 @@ struct CoxParams {
 struct AdamParams {
   float *w, *m, *v;              // flat parameters and Adam moments [n]
   const float* g;                // flat gradients [n]
+  const float* l1_mask;          // [n] in {0, 1}: where the L1 term applies (l1_reg_modules), or null = everywhere
   int64_t n;
   float b1, b2, eps, wd, l1;     // l1 = lambda_reg x accumulated micro-batches
   float step_size, bc2_sqrt;     // lr / (1 - b1^t), sqrt(1 - b2^t)

@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void nll_surv_kernel(NllParams p) {
     float* gH = p.gH + b * p.K;
     float* gS = p.gS + b * p.K;
     for (int k = 0; k < p.K; ++k) { gH[k] = 0.f; gS[k] = 0.f; }
-    const int y = (int)p.Y[b];
+    const int64_t y64 = p.Y[b];
+    if (y64 < 0 || y64 >= p.K) {        // the reference's gather raises; here: NaN loss, zero gradients, no stray access
+      l = __builtin_nanf("");
+      continue;
+    }
+    const int y = (int)y64;
     const float c = p.c[b];
     const float sp_y = y == 0 ? 1.0f : S[y - 1];      // S_padded[y]
     const float hy = hz[y];
@@ -166,9 +171,9 @@ __global__ __launch_bounds__(256) void cox_kernel(CoxParams p) {
 __global__ __launch_bounds__(256) void adam_l1_kernel(AdamParams p) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= p.n) return;
-  auto upd = [&](float w, float g, float& m, float& v) {
+  auto upd = [&](float w, float g, float& m, float& v, float l1) {
     const float sg = w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f);
-    const float gg = g + p.l1 * sg + p.wd * w;
+    const float gg = g + l1 * sg + p.wd * w;
     m = p.b1 * m + (1.f - p.b1) * gg;
     v = p.b2 * v + (1.f - p.b2) * gg * gg;
     const float denom = sqrtf(v) / p.bc2_sqrt + p.eps;
@@ -176,13 +181,15 @@ __global__ __launch_bounds__(256) void adam_l1_kernel(AdamParams p) {
   };
   if (i4 + 3 < p.n) {
     float4 w = ld4(p.w + i4), g = ld4(p.g + i4), m = ld4(p.m + i4), v = ld4(p.v + i4);
-    w.x = upd(w.x, g.x, m.x, v.x); w.y = upd(w.y, g.y, m.y, v.y);
-    w.z = upd(w.z, g.z, m.z, v.z); w.w = upd(w.w, g.w, m.w, v.w);
+    float4 k = make_float4(p.l1, p.l1, p.l1, p.l1);
+    if (p.l1_mask) { const float4 q = ld4(p.l1_mask + i4); k.x *= q.x; k.y *= q.y; k.z *= q.z; k.w *= q.w; }
+    w.x = upd(w.x, g.x, m.x, v.x, k.x); w.y = upd(w.y, g.y, m.y, v.y, k.y);
+    w.z = upd(w.z, g.z, m.z, v.z, k.z); w.w = upd(w.w, g.w, m.w, v.w, k.w);
     st4(p.w + i4, w); st4(p.m + i4, m); st4(p.v + i4, v);
   } else {
     for (int64_t i = i4; i < p.n; ++i) {
       float m = p.m[i], v = p.v[i];
-      p.w[i] = upd(p.w[i], p.g[i], m, v);
+      p.w[i] = upd(p.w[i], p.g[i], m, v, p.l1_mask ? p.l1 * p.l1_mask[i] : p.l1);
       p.m[i] = m; p.v[i] = v;
     }
   }

@@ -22,20 +22,23 @@ class FlatGradBuffer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # [n gradients | 2 control words]: the control words travel in the same collective (utils/core_utils.py)
+        self.bucket = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self.flat = self.bucket[:n]
+        self.tail = self.bucket[n:]
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        self.bucket.zero_()
 
     def all_reduce(self, group=None):
         """One SUM all-reduce (RCCL on GPUs; gloo in the CPU tests).  A bucket of 1.6-34 MB: with 7 direct
         xGMI links per GPU this is latency- to per-link-bandwidth-bound, so it is never split."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=group)
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None):

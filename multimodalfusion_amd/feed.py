@@ -93,3 +93,64 @@ class DevicePrefetcher:
             except StopIteration:
                 pass
             yield out
+
+
+# ---- rank sharding of the training loader (one-bag-per-GPU data parallelism) ------------------------------------
+class _StridedBatches(torch.utils.data.Sampler):
+    """Batch sampler of rank r: every world-th batch of the base batch sampler's order for this epoch.  The order is
+    drawn ONCE, on rank 0, and broadcast, so the ranks agree on it by construction (a RandomSampler draws its
+    permutation from the global torch RNG, which nothing guarantees to be in the same state on every rank)."""
+
+    def __init__(self, base, rank, world):
+        self.base, self.rank, self.world = base, rank, world
+        self.n_total = len(base)
+
+    def __iter__(self):
+        import torch.distributed as dist
+        order = [list(b) for b in self.base] if self.rank == 0 else None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [order]
+            dist.broadcast_object_list(box, src=0)
+            order = box[0]
+        elif order is None:
+            order = [list(b) for b in self.base]
+        self.n_total = len(order)
+        return iter(order[self.rank::self.world])
+
+    def __len__(self):
+        return (self.n_total - self.rank + self.world - 1) // self.world
+
+
+class RankShard:
+    """The part of `loader` that rank `rank` of `world` processes: loader positions rank, rank + world, ... --
+    only those bags are read from disk, collated and copied.  Iterating yields the reference's batch tuples in
+    position order; `n_total` is the length of the whole (unsharded) loader, `position(i)` the loader position of the
+    i-th yielded batch.  Works for a torch DataLoader (a new DataLoader over the same dataset whose batch sampler is
+    the strided view of the original one), for a DevicePrefetcher around one, for indexable sequences, and for any
+    other sized iterable (there the skipped items are still produced by the iterable, then dropped)."""
+
+    def __init__(self, loader, rank: int, world: int):
+        self.rank, self.world = int(rank), int(world)
+        self.n_total = len(loader)
+        self._src = self._shard(loader)
+
+    def _shard(self, loader):
+        r, w = self.rank, self.world
+        if isinstance(loader, DevicePrefetcher):
+            return DevicePrefetcher(self._shard(loader.loader), loader.device, loader.depth, loader.path_dtype)
+        if isinstance(loader, torch.utils.data.DataLoader):
+            kw = dict(collate_fn=loader.collate_fn, num_workers=loader.num_workers, pin_memory=loader.pin_memory,
+                      timeout=loader.timeout, worker_init_fn=loader.worker_init_fn)
+            if loader.num_workers > 0:
+                kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers)
+            return torch.utils.data.DataLoader(loader.dataset, batch_sampler=_StridedBatches(loader.batch_sampler, r, w), **kw)
+        if hasattr(loader, "__getitem__"):
+            return (loader[i] for i in range(r, self.n_total, w))
+        import itertools
+        return itertools.islice(iter(loader), r, None, w)
+
+    def position(self, i: int) -> int:
+        return self.rank + i * self.world
+
+    def __iter__(self):
+        return iter(self._src)

@@ -4,15 +4,19 @@ step against 0.1-0.3 ms of kernels).
 `GraphedStep(fn)` captures `fn()` -- typically zero-grads + model(**static_inputs) + loss + backward, all on
 fixed-shape static tensors -- into one hipGraph and replays it.  The C ABI launches on the capture stream, allocates
 nothing and never synchronises, so capture needs nothing special from the kernels except the dropout seed: a by-value
-seed would be frozen into the captured kernel arguments and every replay would draw the same mask.  The library
-therefore adds a device-resident word to every dropout key (mmf_set_device_seed); the first node of the graph bumps
-that word, so replay r uses effective seed = host seed + seed0 + r * BUMP (uint32 wrap), reproducibly.
+seed would be frozen into the captured kernel arguments and every replay would draw the same mask.  Every dropout-
+bearing entry point therefore takes an optional device-resident word that the kernels add to their keys
+(mmf_amil_desc::seed_dev and the `seed_dev` arguments, include/mmf_amil.h); the first node of the graph bumps that
+word, so replay r uses effective seed = host seed + seed0 + r * BUMP (uint32 wrap), reproducibly.  The word is an
+argument of each call, not library state: ops.py passes the DeviceSeed that is current while the step is captured
+and each autograd node hands the same word to its backward, so graphed and eager steps, or two graphed models, can
+live in one process.
 """
 from __future__ import annotations
 
 import torch
 
-from ._lib import lib, ptr
+from . import ops
 
 SEED_BUMP = 0x6B43A9B5
 
@@ -23,12 +27,12 @@ def _as_i32(v: int) -> int:
 
 
 class DeviceSeed:
-    """Registers a device word that every kernel adds to its dropout keys; unregisters on close()."""
+    """A device word that the kernels launched inside `with seed:` add to their dropout keys."""
 
     def __init__(self, value: int = 0, device=None):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.word = torch.full((1,), _as_i32(value), dtype=torch.int32, device=dev)
-        lib().mmf_set_device_seed(ptr(self.word))
+        self._prev = []
 
     def bump(self):
         self.word.add_(_as_i32(SEED_BUMP))       # int32 add wraps like uint32
@@ -36,14 +40,12 @@ class DeviceSeed:
     def value(self) -> int:
         return int(self.word.item()) & 0xFFFFFFFF
 
-    def close(self):
-        lib().mmf_set_device_seed(None)
-
     def __enter__(self):
+        self._prev.append(ops.set_device_seed(self.word))
         return self
 
     def __exit__(self, *a):
-        self.close()
+        ops.set_device_seed(self._prev.pop())
 
 
 class GraphedStep:
@@ -51,20 +53,21 @@ class GraphedStep:
         self.seed = DeviceSeed(seed0)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):               # warm-up off the default stream (allocator pools, LDS attributes)
-            for _ in range(warmup):
-                self.seed.bump()
-                fn()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.seed.bump()                     # first node: fresh dropout masks on every replay
-            self.out = fn()
+        with self.seed:                          # the word is passed to the launches made in here, nowhere else
+            with torch.cuda.stream(s):           # warm-up off the default stream (allocator pools, LDS attributes)
+                for _ in range(warmup):
+                    self.seed.bump()
+                    fn()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.seed.bump()                 # first node: fresh dropout masks on every replay
+                self.out = fn()
 
     def __call__(self):
         self.graph.replay()
         return self.out
 
     def close(self):
-        self.seed.close()
+        """Nothing to unregister (the seed word is a per-call argument); kept for callers of the earlier interface."""

@@ -16,6 +16,34 @@ ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}
 
 _drop_calls = 0
 
+# Host-side plumbing state for two optional per-call ABI arguments (the library itself keeps no state):
+#   _seed_word  a device int32 word added to every dropout seed (graph.DeviceSeed sets it while it captures / replays a
+#               hipGraph); each autograd node remembers the word its forward used, so its backward uses the same one;
+#   _trace      an mmf_trace handle (bench.py's roofline leg: per-kernel HIP-event timing on the launch stream).
+_seed_word = None
+_trace = None
+
+
+def set_device_seed(word):
+    """word: int32 CUDA tensor [1] or None.  Returns the previous one."""
+    global _seed_word
+    prev, _seed_word = _seed_word, word
+    return prev
+
+
+def set_trace(handle):
+    global _trace
+    prev, _trace = _trace, handle
+    return prev
+
+
+def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, seed_word):
+    return AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+                    W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
+                    Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
+                    Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF,
+                    seed_dev=ptr(seed_word), trace=_trace)
+
 
 def next_dropout_seed() -> int:
     """Per-call dropout seed: deterministic given torch.manual_seed(), no device sync."""
@@ -52,10 +80,8 @@ class AmilPoolFn(torch.autograd.Function):
         H, D = W1.shape[0], Wa.shape[0]
         if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D:
             raise _lib.MmfError("attention stack shapes do not match the bag")
-        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
-                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
-                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
-                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF)
+        word = _seed_word
+        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, word)
         l = lib()
         ws_fn, fwd_fn = ((l.mmf_amil_bf16_workspace_bytes, l.mmf_amil_bf16_forward) if bf16
                          else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
@@ -67,6 +93,7 @@ class AmilPoolFn(torch.autograd.Function):
               "mmf_amil_bf16_forward" if bf16 else "mmf_amil_forward")
         ctx.bf16 = bf16
         ctx.desc_args = (N, L, H, D, bool(gated), float(p_h), float(p_att), int(seed) & 0xFFFFFFFF)
+        ctx.seed_word = word
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw)
         return M, A_raw
@@ -78,10 +105,7 @@ class AmilPoolFn(torch.autograd.Function):
         dev = x.device
         gM = torch.zeros((1, H), dtype=torch.float32, device=dev) if gM is None else _f32c(gM)
         gA = _f32c(gA) if gA is not None else None
-        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
-                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
-                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
-                     Wc=ptr(Wc), bc=ptr(bc), p_h=p_h, p_att=p_att, seed=seed)
+        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, ctx.seed_word)
         new = lambda ref: torch.empty_like(ref)
         dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
         dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
@@ -109,10 +133,7 @@ def amil_infer(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated):
     H, D = W1.shape[0], Wa.shape[0]
     if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D:
         raise _lib.MmfError("attention stack shapes do not match the bag")
-    d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
-                 W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
-                 Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
-                 Wc=ptr(Wc), bc=ptr(bc), p_h=0.0, p_att=0.0, seed=0)
+    d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, 0.0, 0.0, 0, None)
     l = lib()
     ws_fn, fn, name = ((l.mmf_amil_bf16_infer_workspace_bytes, l.mmf_amil_bf16_infer, "mmf_amil_bf16_infer") if bf16
                        else (l.mmf_amil_infer_workspace_bytes, l.mmf_amil_infer, "mmf_amil_infer"))
@@ -139,15 +160,17 @@ class AmilHeadFn(torch.autograd.Function):
     def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h, p_att, seed):
         bf16 = x.dtype == torch.bfloat16
         x = x.contiguous() if bf16 else _f32c(x)
+        W1, b1, Wa, ba, Wc, bc, Wk, bk = map(_f32c, (W1, b1, Wa, ba, Wc, bc, Wk, bk))   # model.half() / .double() must not
+        Wb, bb = _f32c(Wb), _f32c(bb)                                                    # reach the fp32 kernels
+        if x.dim() != 2:
+            raise _lib.MmfError(f"bag must be [N x L], got {tuple(x.shape)}")
         N, L = x.shape
         H, D, K = W1.shape[0], Wa.shape[0], Wk.shape[0]
         if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D or Wk.shape[1] != H:
             raise _lib.MmfError("attention stack / classifier shapes do not match the bag")
         seed = int(seed) & 0xFFFFFFFF
-        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
-                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
-                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
-                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=seed)
+        word = _seed_word
+        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, word)
         l = lib()
         ws_fn, fwd_fn = ((l.mmf_amil_bf16_workspace_bytes, l.mmf_amil_bf16_forward) if bf16
                          else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
@@ -163,6 +186,7 @@ class AmilHeadFn(torch.autograd.Function):
         check(l.mmf_surv_head_forward(ptr(M), ptr(Wk), ptr(bk), 1, H, K, ptr(out[0]), ptr(out[1]), ptr(out[2]),
                                       ptr(Y_hat), st), "mmf_surv_head_forward")
         ctx.cfg = (N, L, H, D, K, bool(gated), float(p_h), float(p_att), seed, bf16)
+        ctx.seed_word = word
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, M, A_raw, out)
         ctx.mark_non_differentiable(Y_hat)
@@ -185,10 +209,7 @@ class AmilHeadFn(torch.autograd.Function):
         dbk = torch.empty((K,), dtype=torch.float32, device=dev)
         check(l.mmf_surv_head_backward(ptr(gH), ptr(gS), ptr(out[1]), ptr(M), ptr(Wk), 1, H, K,
                                        ptr(dM), ptr(dWk), ptr(dbk), st), "mmf_surv_head_backward")
-        d = AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
-                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
-                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
-                     Wc=ptr(Wc), bc=ptr(bc), p_h=p_h, p_att=p_att, seed=seed)
+        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, ctx.seed_word)
         new = torch.empty_like
         dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
         dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
@@ -228,7 +249,7 @@ class LinearCatFn(torch.autograd.Function):
             raise _lib.MmfError("weight does not match the concatenated width")
         y = torch.empty((M, N), dtype=torch.float32, device=W.device)
         segs = (C.c_void_p * nseg)(*[ptr(x) for x in xs])
-        check(lib().mmf_linear_forward(segs, nseg, kseg, M, ptr(W), ptr(b), N, ACT["none"], 0.0, 0, 0,
+        check(lib().mmf_linear_forward(segs, nseg, kseg, M, ptr(W), ptr(b), N, ACT["none"], 0.0, 0, 0, None,
                                        ptr(y), stream_ptr()), "mmf_linear_forward")
         ctx.save_for_backward(W, *xs)
         ctx.has_bias = b is not None
@@ -305,8 +326,11 @@ class NllSurvFn(torch.autograd.Function):
     def forward(ctx, hazards, S, Y, c, alpha, eps):
         hazards, S = _f32c(hazards), _f32c(S)
         B, K = hazards.shape
-        Y = Y.reshape(B).to(torch.int64).contiguous()
-        c = c.reshape(B).to(torch.float32).contiguous()
+        if not Y.is_cuda:       # labels still on the host: validate for free (the reference's gather raises IndexError);
+            if bool(((Y < 0) | (Y >= K)).any()):       # device labels are checked by the kernel (NaN loss, no stray access)
+                raise IndexError(f"nll_surv: label out of range [0, {K})")
+        Y = Y.reshape(B).to(device=hazards.device, dtype=torch.int64).contiguous()
+        c = c.reshape(B).to(device=hazards.device, dtype=torch.float32).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=hazards.device)
         g = torch.empty((2, B, K), dtype=torch.float32, device=hazards.device)     # [d/d hazards ; d/d S]
         check(lib().mmf_nll_surv(ptr(hazards), ptr(S), ptr(Y), ptr(c), B, K, float(alpha), float(eps),
@@ -366,9 +390,11 @@ class DenseFn(torch.autograd.Function):
         if W.shape[1] != K:
             raise _lib.MmfError(f"dense: weight {tuple(W.shape)} does not match input {tuple(x.shape)}")
         y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        word = _seed_word
         check(lib().mmf_dense_forward(ptr(x), ptr(W), ptr(b), B, K, N, ACT[act], DROP_KIND[drop_kind], float(drop_p),
-                                      int(seed) & 0xFFFFFFFF, int(site), ptr(y), stream_ptr()), "mmf_dense_forward")
+                                      int(seed) & 0xFFFFFFFF, int(site), ptr(word), ptr(y), stream_ptr()), "mmf_dense_forward")
         ctx.cfg = (act, drop_kind, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), b is not None)
+        ctx.seed_word = word
         ctx.save_for_backward(x, W, y)
         return y
 
@@ -384,8 +410,8 @@ class DenseFn(torch.autograd.Function):
         dW = torch.empty_like(W)
         db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None
         check(lib().mmf_dense_backward(ptr(gy), ptr(y), ptr(x), ptr(W), B, K, N, ACT[act], DROP_KIND[drop_kind],
-                                       drop_p, seed, site, ptr(dpre), ptr(dx), ptr(dW), ptr(db), stream_ptr()),
-              "mmf_dense_backward")
+                                       drop_p, seed, site, ptr(ctx.seed_word), ptr(dpre), ptr(dx), ptr(dW), ptr(db),
+                                       stream_ptr()), "mmf_dense_backward")
         return dx, dW, db, None, None, None, None, None
 
 
@@ -429,9 +455,11 @@ class KronFn(torch.autograd.Function):
         total = (dim + 1) ** m
         out = torch.empty((B, total), dtype=torch.float32, device=os_[0].device)
         arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
-        check(lib().mmf_kron_forward(arr, m, dim, B, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(out),
+        word = _seed_word
+        check(lib().mmf_kron_forward(arr, m, dim, B, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(word), ptr(out),
                                      stream_ptr()), "mmf_kron_forward")
         ctx.cfg = (float(drop_p), int(seed) & 0xFFFFFFFF, int(site))
+        ctx.seed_word = word
         ctx.save_for_backward(*os_)
         return out
 
@@ -445,7 +473,7 @@ class KronFn(torch.autograd.Function):
         ds = [torch.empty_like(o) for o in os_]
         arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
         darr = (C.c_void_p * m)(*[ptr(d) for d in ds])
-        check(lib().mmf_kron_backward(ptr(g), arr, m, dim, B, drop_p, seed, site, darr, stream_ptr()),
+        check(lib().mmf_kron_backward(ptr(g), arr, m, dim, B, drop_p, seed, site, ptr(ctx.seed_word), darr, stream_ptr()),
               "mmf_kron_backward")
         return (None, None, None) + tuple(ds)
 
@@ -455,16 +483,16 @@ def kron_ones(os_, drop_p=0.0, seed=0, site=0):
 
 
 # ---- raw (no-autograd) launch helpers shared by the fused fusion Function --------------------------------------
-def _dense_fwd_raw(x, W, b, act, kind, p, seed, site):
+def _dense_fwd_raw(x, W, b, act, kind, p, seed, site, word=None):
     B, K = x.shape
     N = W.shape[0]
     y = torch.empty((B, N), dtype=torch.float32, device=x.device)
     check(lib().mmf_dense_forward(ptr(x), ptr(W), ptr(b), B, K, N, ACT[act], DROP_KIND[kind], float(p), seed, site,
-                                  ptr(y), stream_ptr()), "mmf_dense_forward")
+                                  ptr(word), ptr(y), stream_ptr()), "mmf_dense_forward")
     return y
 
 
-def _dense_bwd_raw(gy, y, x, W, has_bias, act, kind, p, seed, site, need_dx=True):
+def _dense_bwd_raw(gy, y, x, W, has_bias, act, kind, p, seed, site, need_dx=True, word=None):
     B, K = x.shape
     N = W.shape[0]
     dpre = torch.empty_like(y)
@@ -472,7 +500,7 @@ def _dense_bwd_raw(gy, y, x, W, has_bias, act, kind, p, seed, site, need_dx=True
     dW = torch.empty_like(W)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if has_bias else None
     check(lib().mmf_dense_backward(ptr(gy), ptr(y), ptr(x), ptr(W), B, K, N, ACT[act], DROP_KIND[kind], float(p), seed,
-                                   site, ptr(dpre), ptr(dx), ptr(dW), ptr(db), stream_ptr()), "mmf_dense_backward")
+                                   site, ptr(word), ptr(dpre), ptr(dx), ptr(dW), ptr(db), stream_ptr()), "mmf_dense_backward")
     return dx, dW, db
 
 
@@ -486,9 +514,11 @@ class MlpFn(torch.autograd.Function):
         x = _f32c(x)
         seed = int(seed) & 0xFFFFFFFF
         acts = [x]
+        word = _seed_word
         for i, (act, kind, p, site) in enumerate(spec):
-            acts.append(_dense_fwd_raw(acts[-1], wb[2 * i], wb[2 * i + 1], act, kind, p, seed, site))
+            acts.append(_dense_fwd_raw(acts[-1], wb[2 * i], wb[2 * i + 1], act, kind, p, seed, site, word))
         ctx.cfg = (spec, seed)
+        ctx.seed_word = word
         ctx.save_for_backward(*acts, *wb)
         return acts[-1]
 
@@ -504,7 +534,7 @@ class MlpFn(torch.autograd.Function):
             act, kind, p, site = spec[i]
             need_dx = i > 0 or ctx.needs_input_grad[2]
             g, dW, db = _dense_bwd_raw(g, acts[i + 1], acts[i], wb[2 * i], wb[2 * i + 1] is not None, act, kind, p, seed,
-                                       site, need_dx=need_dx)
+                                       site, need_dx=need_dx, word=ctx.seed_word)
             grads[2 * i], grads[2 * i + 1] = dW, db
         return (None, None, g) + tuple(grads)
 
@@ -537,16 +567,18 @@ class XFusionFn(torch.autograd.Function):
         new = lambda: [torch.empty((B, sdim), dtype=torch.float32, device=vs[0].device) for _ in range(m)]
         hs, zs, gms, os_ = new(), new(), new(), new()
         io = XFusionFn._io(m, vs, w, hs, zs, gms, os_)
-        check(lib().mmf_xreduce_forward(C.byref(io), float(p), seed, stream_ptr()), "mmf_xreduce_forward")
+        word = _seed_word
+        check(lib().mmf_xreduce_forward(C.byref(io), float(p), seed, ptr(word), stream_ptr()), "mmf_xreduce_forward")
         We1, be1, We2, be2 = w[6 * m:6 * m + 4]
         B, dim = os_[0].shape
         kr = torch.empty((B, (dim + 1) ** m), dtype=torch.float32, device=vs[0].device)
         arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
-        check(lib().mmf_kron_forward(arr, m, dim, B, float(p), seed, 8, ptr(kr), stream_ptr()), "mmf_kron_forward")
-        e1 = _dense_fwd_raw(kr, We1, be1, "relu", kind, p, seed, 9)
+        check(lib().mmf_kron_forward(arr, m, dim, B, float(p), seed, 8, ptr(word), ptr(kr), stream_ptr()), "mmf_kron_forward")
+        e1 = _dense_fwd_raw(kr, We1, be1, "relu", kind, p, seed, 9, word)
         cat2 = torch.cat([e1] + vs, dim=1)
-        e2 = _dense_fwd_raw(cat2, We2, be2, "relu", kind, p, seed, 10)
+        e2 = _dense_fwd_raw(cat2, We2, be2, "relu", kind, p, seed, 10, word)
         ctx.cfg = (m, float(p), seed, kind)
+        ctx.seed_word = word
         ctx.save_for_backward(*vs, *w, *hs, *zs, *gms, *os_, kr, e1, cat2, e2)
         return e2
 
@@ -570,16 +602,17 @@ class XFusionFn(torch.autograd.Function):
         kr, e1, cat2, e2 = t[4 * m:4 * m + 4]
         We1, be1, We2, be2 = w[6 * m:6 * m + 4]
         g = _f32c(g)
-        d_cat2, dWe2, dbe2 = _dense_bwd_raw(g, e2, cat2, We2, True, "relu", kind, p, seed, 10)
+        word = ctx.seed_word
+        d_cat2, dWe2, dbe2 = _dense_bwd_raw(g, e2, cat2, We2, True, "relu", kind, p, seed, 10, word=word)
         H1 = e1.shape[1]
         d_e1 = d_cat2[:, :H1].contiguous()
         dim_v = vs[0].shape[1]
-        d_kr, dWe1, dbe1 = _dense_bwd_raw(d_e1, e1, kr, We1, True, "relu", kind, p, seed, 9)
+        d_kr, dWe1, dbe1 = _dense_bwd_raw(d_e1, e1, kr, We1, True, "relu", kind, p, seed, 9, word=word)
         B, dim = os_[0].shape
         d_os = [torch.empty_like(o) for o in os_]
         arr = (C.c_void_p * m)(*[ptr(o) for o in os_])
         darr = (C.c_void_p * m)(*[ptr(d) for d in d_os])
-        check(lib().mmf_kron_backward(ptr(d_kr), arr, m, dim, B, p, seed, 8, darr, stream_ptr()), "mmf_kron_backward")
+        check(lib().mmf_kron_backward(ptr(d_kr), arr, m, dim, B, p, seed, 8, ptr(word), darr, stream_ptr()), "mmf_kron_backward")
         io = XFusionFn._io(m, vs, w, hs, zs, gms, os_)
         dvs = [torch.empty_like(v) for v in vs]
         grads_w = []
@@ -589,7 +622,7 @@ class XFusionFn(torch.autograd.Function):
             io.d_o[i] = ptr(d_os[i]); io.dv[i] = ptr(dvs[i])
             io.dWh[i], io.dbh[i], io.dWz[i], io.dbz[i], io.dWo[i], io.dbo[i] = [ptr(x) for x in gw]
             grads_w += gw
-        check(lib().mmf_xreduce_backward(C.byref(io), p, seed, stream_ptr()), "mmf_xreduce_backward")
+        check(lib().mmf_xreduce_backward(C.byref(io), p, seed, ptr(word), stream_ptr()), "mmf_xreduce_backward")
         for i in range(m):      # skip connection: encoder2 saw the v_i directly
             dvs[i] += d_cat2[:, H1 + dim_v * i: H1 + dim_v * (i + 1)]
         return (None, None, None) + tuple(dvs) + tuple(grads_w) + (dWe1, dbe1, dWe2, dbe2)
@@ -612,11 +645,13 @@ class BatchNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty((F,), dtype=torch.float32, device=x.device)
         invstd = torch.empty_like(mean)
+        word = _seed_word
         check(lib().mmf_batchnorm_forward(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                           B, F, 1 if training else 0, float(eps), float(momentum), ACT[act],
-                                          float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(y), ptr(mean), ptr(invstd),
-                                          stream_ptr()), "mmf_batchnorm_forward")
+                                          float(drop_p), int(seed) & 0xFFFFFFFF, int(site), ptr(word), ptr(y), ptr(mean),
+                                          ptr(invstd), stream_ptr()), "mmf_batchnorm_forward")
         ctx.cfg = (bool(training), act, float(drop_p), int(seed) & 0xFFFFFFFF, int(site), res is not None)
+        ctx.seed_word = word
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         return y
 
@@ -631,7 +666,7 @@ class BatchNormFn(torch.autograd.Function):
         dgamma = torch.empty_like(mean)
         dbeta = torch.empty_like(mean)
         check(lib().mmf_batchnorm_backward(ptr(gy), ptr(y), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), B, F,
-                                           1 if training else 0, ACT[act], drop_p, seed, site,
+                                           1 if training else 0, ACT[act], drop_p, seed, site, ptr(ctx.seed_word),
                                            ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), stream_ptr()),
               "mmf_batchnorm_backward")
         return dx, dres, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), \

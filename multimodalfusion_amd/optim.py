@@ -17,7 +17,9 @@ from ._lib import check, lib, ptr, stream_ptr
 
 class FlatAdam:
     def __init__(self, model: torch.nn.Module, lr=2e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
-                 lambda_l1=0.0):
+                 lambda_l1=0.0, l1_modules=None):
+        """l1_modules: None = the L1 term covers every parameter (`l1_reg_all`, utils/utils.py:249-257); a list of
+        sub-modules = only their parameters (`l1_reg_modules`, utils/utils.py:259-268: model.fc_omic and model.mm)."""
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -25,7 +27,16 @@ class FlatAdam:
         n = sum(p.numel() for p in self.params)
         self.n = n
         self.flat_w = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradient bucket: [n gradients | 2 control words].  The control words ride along in the one all-reduce of a
+        # data-parallel step (utils/core_utils.py: "did the window's last bag run" and "bags kept in the window").
+        self.bucket = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self.flat_g = self.bucket[:n]
+        self.tail = self.bucket[n:]
+        self.l1_mask = None
+        if l1_modules is not None:
+            chosen = {id(p) for m in l1_modules for p in m.parameters()}
+            self.l1_mask = torch.cat([torch.full((p.numel(),), 1.0 if id(p) in chosen else 0.0, device=dev)
+                                      for p in self.params])
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
@@ -48,22 +59,24 @@ class FlatAdam:
     def all_reduce(self, group=None):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=group)
 
     def zero_grad(self, set_to_none: bool = False):
-        self.flat_g.zero_()
+        self.bucket.zero_()
 
     def zero(self):
-        self.flat_g.zero_()
+        self.bucket.zero_()
 
     def step(self, l1_micro_batches: int = 0):
         self.t += 1
         check(lib().mmf_adam_l1_step(ptr(self.flat_w), ptr(self.flat_g), ptr(self.m), ptr(self.v), self.n,
                                      self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                     self.lambda_l1 * l1_micro_batches, self.t, stream_ptr()), "mmf_adam_l1_step")
+                                     self.lambda_l1 * l1_micro_batches, ptr(self.l1_mask), self.t, stream_ptr()),
+              "mmf_adam_l1_step")
 
     def l1_value(self):
         """lambda_l1 * sum_W |W| (what `reg_fn(model) * lambda_reg` evaluates to), device scalar."""
         out = torch.empty((), dtype=torch.float32, device=self.flat_w.device)
-        check(lib().mmf_abs_sum(ptr(self.flat_w), self.n, ptr(self._partials), ptr(out), stream_ptr()), "mmf_abs_sum")
+        w = self.flat_w if self.l1_mask is None else self.flat_w * self.l1_mask
+        check(lib().mmf_abs_sum(ptr(w), self.n, ptr(self._partials), ptr(out), stream_ptr()), "mmf_abs_sum")
         return out * self.lambda_l1

@@ -31,13 +31,23 @@ class BagsInFlight:
         for s in self.streams:
             s.wait_stream(cur)
 
-    def run(self, loss_fn_of_model_call, accumulate: bool = True):
+    def run(self, loss_fn_of_model_call, accumulate: bool = True, inputs=()):
         """Issue one bag: `loss_fn_of_model_call()` must run the forward and return the scalar loss; its gradients are
         added to (accumulate=True) or written over (False) the slot of the stream the bag runs on.  Returns the loss
-        (a tensor living on that stream; read it after `join()`)."""
+        (a tensor living on that stream; read it after `join()`).
+
+        `inputs`: the device tensors the closure reads (the bag and its labels).  They were produced on the caller's
+        current stream -- an H2D copy, a bf16 narrowing, or feed.DevicePrefetcher's hand-over, which orders them
+        behind the CURRENT stream only -- so the side stream first waits for everything issued there so far, and the
+        caching allocator is told that the side stream uses them (otherwise a freed bag could be handed to the next
+        bag's copy while this bag's backward, dW1 = du^T x, is still reading it)."""
         i = self._count % self.n
         self._count += 1
         st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        for t in inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             loss = loss_fn_of_model_call()
             grads = torch.autograd.grad(loss, self.params)

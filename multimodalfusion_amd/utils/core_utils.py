@@ -6,8 +6,8 @@ HIP kernels through the drop-in modules; this file is host control flow only.
 Differences, all outside the arithmetic:
   * the c-index is computed with a small numpy restatement of sksurv's concordance_index_censored (sksurv is
     not a dependency of this package);
-  * optional one-bag-per-GPU data parallelism (`dp=True` under torch.distributed): each rank takes every
-    world_size-th bag and the flat gradient buffer is all-reduced once per optimizer step (see dp.py);
+  * optional one-bag-per-GPU data parallelism (`dp=True` under torch.distributed): the loader is sharded by rank
+    (feed.RankShard) and the flat gradient bucket is all-reduced once per optimizer step (see dp.py);
   * host synchronisation (`loss.item()`) is deferred to the end of the epoch instead of every bag.
 """
 from __future__ import annotations
@@ -65,99 +65,180 @@ def _skip(mode, radio_features, path_features, genomic_features):
     return False
 
 
+class _Window:
+    """Gradient accumulation window of `train_loop_survival`, kept on the optimizer object between calls because the
+    reference's accumulated gradients survive the end of an epoch (a trailing partial window is NOT stepped and NOT
+    cleared, utils/core_utils.py:245-247: its gradients join the first window of the next epoch).
+
+    Three ways to hold the window's gradient, one interface:
+      fused   FlatAdam: p.grad are views of its flat bucket [n grads | 2 control words];
+      buffer  any torch optimizer + dp.FlatGradBuffer (made here when world > 1): same bucket layout;
+      plain   any torch optimizer, world == 1: p.grad as autograd leaves them.
+    With `inflight` > 1 (fused only) the bags run on side streams into per-stream slots (pipeline.BagsInFlight) that
+    are folded into the bucket at every boundary and at the end of the epoch."""
+
+    def __init__(self, model, optimizer, world, grad_buffer, inflight, device):
+        self.opt, self.world = optimizer, world
+        self.fused = isinstance(optimizer, FlatAdam)
+        self.buf = None if self.fused else grad_buffer
+        if world > 1 and not self.fused and self.buf is None:
+            self.buf = FlatGradBuffer(model)
+        self.pipe = None
+        if inflight > 1:
+            if not self.fused:
+                raise ValueError("inflight > 1 needs the FlatAdam optimizer (flat gradient buffer)")
+            from ..pipeline import BagsInFlight
+            self.pipe = BagsInFlight(model, inflight, device)
+        self.kept = 0            # bags that contributed since the last optimizer step (this rank)
+
+    @property
+    def bucket(self):
+        return self.opt.bucket if self.fused else (self.buf.bucket if self.buf is not None else None)
+
+    def fold(self):
+        """Side-stream slots -> the flat bucket (also called at the end of an epoch so that nothing is left in flight)."""
+        if self.pipe is not None and any(self.pipe._used):
+            self.opt.flat_g.add_(self.pipe.reduce(all_reduce=False))
+
+    def boundary(self, last_bag_ran):
+        """A window's last loader position has been passed.  The reference steps there only when that bag was not
+        skipped (its `continue` jumps over the step, so the gradients stay and the window merges with the next one).
+        world > 1: ONE all-reduce of [grads | ran-flag | kept-count]; every rank takes the same decision from the
+        reduced control words (`last_bag_ran` is known to the rank that owns the window's last position only)."""
+        self.fold()
+        ran, kept = bool(last_bag_ran), self.kept
+        if self.world > 1:
+            tail = self.bucket[-2:]
+            tail[0] += 1.0 if last_bag_ran else 0.0
+            tail[1] += float(self.kept)
+            (self.opt if self.fused else self.buf).all_reduce()
+            flag, total = self.bucket[-2:].tolist()         # host sync, once per optimizer step
+            ran, kept = flag > 0.5, int(round(total))
+            if not ran:
+                # no step: the window stays open.  The reduced sum now sits on every rank; keep it on rank 0 only so
+                # that the next all-reduce counts it once.
+                if torch.distributed.get_rank() != 0:
+                    self.bucket.zero_()
+                self.kept = 0
+                if self.pipe is not None:
+                    self.pipe.release()
+                return False
+        if not ran:
+            return False
+        if self.fused:
+            self.opt.step(l1_micro_batches=kept)
+            self.opt.zero_grad()
+        else:
+            self.opt.step()
+            if self.buf is not None:
+                self.buf.zero()
+            else:
+                self.opt.zero_grad()
+        self.kept = 0
+        if self.pipe is not None:
+            self.pipe.release()
+        return True
+
+
+def _window_of(model, optimizer, world, grad_buffer, inflight, device):
+    key = (world, inflight, id(model))
+    w = getattr(optimizer, "_mmf_window", None)
+    if w is None or getattr(w, "key", None) != key:
+        w = _Window(model, optimizer, world, grad_buffer, inflight, device)
+        w.key = key
+        try:
+            optimizer._mmf_window = w
+        except AttributeError:
+            pass
+    return w
+
+
 def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer=None, loss_fn=None, reg_fn=None,
                         lambda_reg=0., gc=16, t_bin=None, dp=False, grad_buffer=None, inflight=1):
-    """utils/core_utils.py:173-264.  Extras (all off by default): `dp` = one bag per rank with one all-reduce per
-    optimizer step; a `FlatAdam` optimizer = fused L1 + Adam tail; `inflight` > 1 (needs FlatAdam) = the bags of an
-    accumulation window run round-robin on that many HIP streams, each into its own gradient slot
-    (pipeline.BagsInFlight)."""
+    """utils/core_utils.py:173-264: same per-bag order (forward, loss, regulariser added AFTER the /gc division,
+    backward), and the same window rule -- the optimizer steps after loader position b when (b + 1) % gc == 0 and bag b
+    was not skipped; skipped bags (missing modality) contribute nothing but still occupy their position.
+
+    Extras, all off by default:
+      dp        one bag per rank (torch.distributed initialised): rank r takes loader positions r, r + world, ...
+                (feed.RankShard: only those bags are loaded); the window is gc x world positions and ends with ONE
+                all-reduce (SUM) of the flat gradient bucket -- the reference's `--gc gc*world`, see dp.py.  Every rank
+                issues exactly one collective per window boundary, whatever it skipped;
+      FlatAdam  fused L1 + Adam tail (optim.py); reg_fn must then be l1_reg_all, or l1_reg_modules with a FlatAdam
+                built with the matching `l1_modules`;
+      inflight  > 1 (needs FlatAdam): the window's bags run round-robin on that many HIP streams (pipeline.py)."""
+    from ..feed import RankShard
+    from .utils import l1_reg_all, l1_reg_modules
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     model.train()
-    pipe = None
-    if inflight > 1:
-        if not isinstance(optimizer, FlatAdam):
-            raise ValueError("inflight > 1 needs the FlatAdam optimizer (flat gradient buffer)")
-        from ..pipeline import BagsInFlight
-        pipe = BagsInFlight(model, inflight, device)
     world, rank = 1, 0
     if dp and torch.distributed.is_available() and torch.distributed.is_initialized():
         world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
-        if grad_buffer is None:
-            grad_buffer = FlatGradBuffer(model)
+    win = _window_of(model, optimizer, world, grad_buffer, inflight, device)
+    fused_tail, pipe = win.fused, win.pipe
+    if fused_tail:
+        if reg_fn is not None and lambda_reg:
+            want_mask = reg_fn is l1_reg_modules
+            if reg_fn not in (l1_reg_all, l1_reg_modules) or want_mask != (optimizer.l1_mask is not None):
+                raise ValueError("FlatAdam applies the L1 term inside its kernel: reg_fn must be l1_reg_all, or "
+                                 "l1_reg_modules with FlatAdam(l1_modules=[model.fc_omic, model.mm])")
+        optimizer.lambda_l1 = lambda_reg if reg_fn is not None else 0.0      # before the first l1_value() / step
+    G = gc * world
+    shard = RankShard(loader, rank, world) if world > 1 else None
+    n_total = shard.n_total if shard is not None else None
     losses, regs, all_risk, all_c, all_t = [], [], [], [], []
-    seen = 0
-    for batch_idx, (radio_features, path_features, genomic_features, label, event_time, c) in enumerate(loader):
-        if _skip(mode, radio_features, path_features, genomic_features):
-            continue
-        if world > 1 and batch_idx % world != rank:
-            continue
-        feats, label, c = _to_device(radio_features, path_features, genomic_features, label, c, device)
+    n_pos = 0
+    for i, batch in enumerate(shard if shard is not None else loader):
+        radio_features, path_features, genomic_features, label, event_time, c = batch
+        pos = shard.position(i) if shard is not None else i
+        n_pos += 1
+        skipped = _skip(mode, radio_features, path_features, genomic_features)
+        if not skipped:
+            feats, label, c = _to_device(radio_features, path_features, genomic_features, label, c, device)
 
-        def forward_loss():
-            hazards, S, Y_hat, _ = model(**feats)
-            if isinstance(loss_fn, CoxSurvLoss):
-                return hazards, loss_fn(risks=hazards, times=torch.as_tensor(np.asarray(event_time)), c=c)
-            if isinstance(loss_fn, NLLSurvLoss):
-                return -torch.sum(S, dim=1), loss_fn(hazards=hazards, S=S, Y=label, c=c)
-            raise NotImplementedError(type(loss_fn))
+            def forward_loss():
+                hazards, S, Y_hat, _ = model(**feats)
+                if isinstance(loss_fn, CoxSurvLoss):
+                    return hazards, loss_fn(risks=hazards, times=torch.as_tensor(np.asarray(event_time)), c=c)
+                if isinstance(loss_fn, NLLSurvLoss):
+                    return -torch.sum(S, dim=1), loss_fn(hazards=hazards, S=S, Y=label, c=c)
+                raise NotImplementedError(type(loss_fn))
 
-        fused_tail = isinstance(optimizer, FlatAdam)
-        if pipe is not None:
-            box = {}
+            if pipe is not None:
+                box = {}
 
-            def bag():
-                box["risk"], box["loss"] = forward_loss()
-                return box["loss"] / (gc * world)
+                def bag():
+                    box["risk"], box["loss"] = forward_loss()
+                    return box["loss"] / G
 
-            pipe.run(bag)
-            risk, loss = box["risk"], box["loss"]
-            loss_reg = optimizer.l1_value() if (reg_fn is not None and lambda_reg) else 0
+                pipe.run(bag, inputs=list(feats.values()) + [label, c])
+                risk, loss = box["risk"], box["loss"]
+            else:
+                risk, loss = forward_loss()
+            if fused_tail:
+                # the L1 term never enters autograd: its gradient (lambda * sign(W) per kept bag) is added inside the
+                # Adam kernel, its value is a device scalar for logging only
+                loss_reg = optimizer.l1_value() if (reg_fn is not None and lambda_reg) else 0
+            else:
+                loss_reg = 0 if reg_fn is None else reg_fn(model) * lambda_reg
             losses.append(loss.detach())
             regs.append(loss_reg.detach() if torch.is_tensor(loss_reg) else torch.tensor(float(loss_reg), device=device))
             all_risk.append(risk.detach().reshape(-1))
             all_c.append(c.detach().reshape(-1))
             all_t.append(np.asarray(event_time).reshape(-1))
-            seen += 1
-            if seen % gc == 0:
-                optimizer.flat_g.copy_(pipe.reduce(all_reduce=world > 1))
-                optimizer.lambda_l1 = lambda_reg if reg_fn is not None else 0.0
-                optimizer.step(l1_micro_batches=gc * world)
-                pipe.release()
-            continue
-        risk, loss = forward_loss()
-        if fused_tail:
-            # fused per-step tail: the L1 term never enters autograd; its gradient (lambda * sign(W) per micro-batch)
-            # is added inside the Adam kernel, its value is a device scalar for logging only
-            loss_reg = optimizer.l1_value() if (reg_fn is not None and lambda_reg) else 0
-        else:
-            loss_reg = 0 if reg_fn is None else reg_fn(model) * lambda_reg
-        losses.append(loss.detach())
-        regs.append(loss_reg.detach() if torch.is_tensor(loss_reg) else torch.tensor(float(loss_reg), device=device))
-        all_risk.append(risk.detach().reshape(-1))
-        all_c.append(c.detach().reshape(-1))
-        all_t.append(np.asarray(event_time).reshape(-1))
-        # the reference: loss = loss / gc + loss_reg ; backward ; step every gc bags (core_utils.py:242-247)
-        if fused_tail:
-            (loss / (gc * world)).backward()
-        else:
-            (loss / (gc * world) + loss_reg).backward()
-        seen += 1
-        if seen % gc == 0:
-            if fused_tail:
-                if world > 1:
-                    optimizer.all_reduce()
-                optimizer.lambda_l1 = lambda_reg if reg_fn is not None else 0.0
-                optimizer.step(l1_micro_batches=gc * world)
-                optimizer.zero_grad()
-                continue
-            if grad_buffer is not None and world > 1:
-                grad_buffer.all_reduce()
-            optimizer.step()
-            if grad_buffer is not None:
-                grad_buffer.zero()
-            else:
-                optimizer.zero_grad()
-    n = max(len(losses), 1)
+            # the reference: loss = loss / gc + loss_reg ; backward (core_utils.py:242-243)
+            if pipe is None:
+                (loss / G if fused_tail else loss / G + loss_reg).backward()
+            win.kept += 1
+        # window boundary: the last position of this rank's window is `last`; (last + 1) % G == 0 as the reference's
+        # (batch_idx + 1) % gc == 0.  With world > 1 `last` belongs to rank world - 1 and must exist in the loader.
+        last = pos + (world - 1 - rank)
+        if (last + 1) % G == 0 and (n_total is None or last < n_total):
+            win.boundary(last_bag_ran=(not skipped) if rank == world - 1 else False)
+    if pipe is not None:
+        pipe.join()                  # the epoch's statistics below read tensors produced on the side streams
+        win.fold()                   # a trailing partial window stays accumulated in the bucket, as in the reference
+    n = max(n_pos, 1)                # the reference divides by len(loader), skipped positions included (:250-251)
     loss_vals = torch.stack(losses).float().cpu().numpy() if losses else np.zeros(0)
     reg_vals = torch.stack(regs).float().cpu().numpy() if regs else np.zeros(0)
     train_loss_surv = float(loss_vals.sum()) / n

@@ -116,3 +116,121 @@ def test_cindex_matches_bruteforce():
     assert abs(concordance_index_censored(e, t, r)[0] - num / den) < 1e-12
     # perfectly ordered risks -> 1.0
     assert concordance_index_censored(np.ones(5, bool), np.arange(5.0), -np.arange(5.0))[0] == 1.0
+
+
+# ---- the training loop itself under DP: rank-sharded loader, skipped bags, odd bag count -------------
+class _StubHead(torch.nn.Module):
+    """CPU stand-in with the drop-in forward contract: forward(**kwargs) -> (hazards, S, Y_hat, A_raw)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.proj = torch.nn.Linear(16, 8)
+        self.cls = torch.nn.Linear(8, 4)
+
+    def forward(self, **kw):
+        h = torch.tanh(self.proj(kw["path_features"])).mean(0, keepdim=True)
+        logits = self.cls(h)
+        hazards = torch.sigmoid(logits)
+        return hazards, torch.cumprod(1 - hazards, dim=1), logits.argmax(1, keepdim=True), None
+
+
+def _stub_loss():
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    from oracle import torch_port as tp
+
+    class CpuNLL(NLLSurvLoss):           # the loop dispatches on the class; the arithmetic here is the CPU oracle's
+        def __call__(self, hazards, S, Y, c, alpha=None):
+            return tp.nll_loss(hazards, S, Y, c, alpha=self.alpha)
+
+    return CpuNLL(alpha=0.0)
+
+
+def _loop_loader():
+    """7 positions (odd), batch tuples as collate_MIL_survival builds them; position 3 -- the LAST position of a window
+    of 2 -- and position 4 hold the dataset's "pathology missing" sentinel."""
+    g = torch.Generator().manual_seed(21)
+    out = []
+    for i in range(7):
+        x = torch.zeros(1, 1) if i in (3, 4) else torch.randn(5 + i, 16, generator=g)
+        out.append(({"T1": torch.zeros(1, 1)}, x, torch.zeros(1, 4), torch.tensor([i % 4]), np.array([float(i)]),
+                    torch.tensor([float(i % 2)])))
+    return out
+
+
+def _run_loop(dp, epochs=2, gc=2):
+    from multimodalfusion_amd.utils import core_utils
+    model = _StubHead()
+    opt = torch.optim.Adam(model.parameters(), lr=LR, weight_decay=1e-5)
+    steps = []
+    step0 = opt.step
+    opt.step = lambda *a, **k: (steps.append(1), step0(*a, **k))[1]
+    for ep in range(epochs):
+        core_utils.train_loop_survival(ep, model, _loop_loader(), opt, 4, "path", loss_fn=_stub_loss(),
+                                       reg_fn=l1_reg_all, lambda_reg=LAM, gc=gc, dp=dp)
+    return [p.detach().numpy().copy() for p in model.parameters()], len(steps)
+
+
+def _loop_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, nsteps = _run_loop(dp=True, gc=1)          # gc 1 x world 2 == the reference's --gc 2
+    q.put((rank, params, nsteps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_loop_dp2_with_skipped_bags_equals_gc2():
+    """train_loop_survival(dp=True) on 2 ranks, a loader with an odd number of positions and two missing-modality
+    sentinels (one of them on a window's last position, where the reference's `continue` also skips the optimizer
+    step): terminates (same number of collectives on every rank), both ranks end with identical parameters, and they
+    equal the single-process run with gc = 2 over the same loader -- including the trailing partial window whose
+    gradients the reference carries into the next epoch."""
+    ref, ref_steps = _run_loop(dp=False, gc=2)
+    # 2 epochs x 7 positions, gc 2: boundaries after positions 1, 3, 5; position 3 is skipped => 2 steps per epoch
+    assert ref_steps == 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, params, nsteps = q.get(timeout=180)
+        got[rank] = (params, nsteps)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == ref_steps
+    for a, b, r in zip(got[0][0], got[1][0], ref):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, r, rtol=1e-5, atol=1e-7)
+
+
+def test_rank_shard_reads_only_its_own_bags():
+    """feed.RankShard over a DataLoader: rank r's dataset sees exactly the indices at loader positions r, r + world, ..."""
+    from multimodalfusion_amd.feed import RankShard
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.seen = []
+
+        def __len__(self):
+            return 9
+
+        def __getitem__(self, i):
+            self.seen.append(i)
+            return torch.tensor([i])
+
+    ds = DS()
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, sampler=torch.utils.data.SequentialSampler(ds))
+    sh = RankShard(loader, 1, 2)
+    got = [int(b[0]) for b in sh]
+    assert got == [1, 3, 5, 7] and ds.seen == got and sh.n_total == 9
+    assert [sh.position(i) for i in range(4)] == got
+    assert list(RankShard(list(range(9)), 0, 4)) == [0, 4, 8]

@@ -13,7 +13,7 @@ for K in (32, 64, 128, 256, 512, 1024):
     segs = (C.c_void_p * 1)(x.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
-        return l.mmf_linear_forward(segs, 1, K, M, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), N, 1, C.c_float(0.25), 7, 0,
+        return l.mmf_linear_forward(segs, 1, K, M, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), N, 1, C.c_float(0.25), 7, 0, None,
                                     C.c_void_p(y.data_ptr()), st)
     for _ in range(20): assert run() == 0
     torch.cuda.synchronize()
