@@ -6,9 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = model(**bag) -> NLLSurvLoss -> backward through the drop-in module surface (the same calls
-utils/core_utils.py:200-243 of the reference makes), bag resident in HBM; N > 1 adds ONE RCCL
-all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == the reference's --gc N).
+A step = forward + NLLSurvLoss + backward of one bag, every parameter gradient written to a flat buffer, bag resident
+in HBM -- issued as the training-loop mirror issues it (multimodalfusion_amd/utils/core_utils.py): ONE C-ABI call,
+`model.nll_step` -> mmf_amil_nll_step (the head and the loss run as the tail of the pooling merge kernel).  The same
+step through the autograd surface (model(**bag) -> NLLSurvLoss -> .backward(), the calls utils/core_utils.py:200-243
+of the reference makes) is timed beside it (`autograd_surface`; `--autograd` makes it the headline).  N > 1 adds ONE
+RCCL all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == the reference's --gc N).
 Train mode as `model.train()` with --drop_out off (one Dropout(0.25) mask, the headline mode of
 BASELINE.md); rank 0 prints ONE JSON line.
 
@@ -45,8 +48,11 @@ def parse():
     ap.add_argument("--eval-mode", action="store_true", help="no dropout (secondary figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bags", type=int, default=8, help="timed bags of the CPU baseline sample")
-    ap.add_argument("--extra-sizes", action="store_true", help="also time N = 1k and 10k (extra keys, same line)")
-    ap.add_argument("--graph", action="store_true", help="also time N = 1k / 10k as captured hipGraph steps (extra key)")
+    ap.add_argument("--no-extras", dest="extras", action="store_false", default=True,
+                    help="skip the extra legs of the default N = 1 run (other bag sizes, hipGraph steps, BASELINE configs "
+                         "3-5, PCIe-inclusive rate); they never change `value`")
+    ap.add_argument("--extra-sizes", action="store_true", help="(kept for older command lines: the legs are on by default)")
+    ap.add_argument("--graph", action="store_true", help="(kept for older command lines: the legs are on by default)")
     ap.add_argument("--h2d", action="store_true", default=True,
                     help="also report the PCIe-inclusive rate (extra key `pcie_inclusive`, never `value`); on by default at N = 1")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false")
@@ -54,6 +60,8 @@ def parse():
                     help="bags in flight per GPU: steps are issued round-robin on this many HIP streams, each with its "
                          "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time; "
                          "0 = default: 3 (fp32), 2 (bf16: its 0.4 ms steps become host-bound beyond two)")
+    ap.add_argument("--autograd", action="store_true",
+                    help="time the step through the autograd surface (model -> loss -> backward) instead of the one-call step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the bag and saved activations; f32 is the BASELINE metric, bf16 is config 5 "
                          "(bf16 MFMA, fp32 accumulate/epilogues; HBM roofline)")
@@ -82,7 +90,15 @@ def build_model(dev, eval_mode):
     return model
 
 
-def make_step(model, x, dev, flat=None, world=1):
+def flat_views(model, flat):
+    off, views = 0, []
+    for p in model.parameters():
+        views.append(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+    return views
+
+
+def make_step(model, x, dev, flat=None, world=1, autograd=False):
     import torch
     import torch.distributed as dist
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
@@ -91,6 +107,19 @@ def make_step(model, x, dev, flat=None, world=1):
     c = torch.tensor([0.0], device=dev)
     inv = 1.0 / world
     params = list(model.parameters())
+    if not autograd:
+        # the one-call step: gradients of loss / world are WRITTEN (not accumulated) into the flat buffer
+        if flat is None:
+            flat = torch.empty(sum(p.numel() for p in params), device=dev)
+        views = flat_views(model, flat)
+
+        def fused():
+            out = model.nll_step(x, Y, c, alpha=0.0, loss_scale=inv, grad_out=views, accumulate=False)
+            if world > 1:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)   # RCCL over xGMI: one collective per step
+            return out[4]
+
+        return fused
 
     def step():
         if flat is not None:
@@ -108,7 +137,7 @@ def make_step(model, x, dev, flat=None, world=1):
     return step
 
 
-def make_step_inflight(model, x, dev, world, n_streams):
+def make_step_inflight(model, x, dev, world, n_streams, autograd=False):
     """The same step (forward + nll_surv + backward, all parameter gradients materialised into a flat buffer, one
     all-reduce per bag when world > 1) with `n_streams` bags in flight: step i runs on stream i % n_streams and owns
     gradient slot i % n_streams."""
@@ -127,7 +156,10 @@ def make_step_inflight(model, x, dev, world, n_streams):
         return loss * inv if world > 1 else loss
 
     def step():
-        loss = pipe.run(bag, accumulate=False)
+        if autograd:
+            loss = pipe.run(bag, accumulate=False)
+        else:
+            loss = pipe.run_fused(model, x, Y, c, 0.0, loss_scale=inv, accumulate=False)[4]
         if world > 1:
             pipe.all_reduce_slot()       # RCCL over xGMI: one collective per bag, on the bag's stream
         return loss
@@ -177,17 +209,84 @@ def step_percentiles(step, steps):
 
 
 def kernel_profile(step, steps):
-    """Per-kernel average duration from HIP events recorded on the launch stream (library hook)."""
+    """Per-kernel average duration from HIP events recorded on the launch stream, inside this process, over `steps`
+    timed steps (include/mmf_amil.h "Kernel trace": the attention-stack entry points record an event pair around
+    every kernel they launch while a trace is attached to their descriptor)."""
     import torch
     from multimodalfusion_amd import _lib
     torch.cuda.synchronize()
-    _lib.profile_enable(True)
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    prof = _lib.profile_dump()
-    _lib.profile_enable(False)
+    with _lib.KernelTrace(capacity=64 * steps) as tr:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        prof = tr.dump()
+    tr.close()
     return {k: dict(launches=n, avg_us=1e3 * ms / max(n, 1)) for k, (n, ms) in prof.items()}
+
+
+def kernel_tables(N, L=1024, H=256, D=256):
+    """Algorithmic FLOPs (fp32 kernels: MFMA-bound) and minimal HBM bytes (bf16-storage kernels: HBM-bound) per
+    launch of each main kernel for one N x L bag of the `small` gated stack."""
+    kflops = {
+        "linear_nt_kernel": 2 * L * H * N,
+        "gate_fwd_kernel": 2 * 2 * H * D * N,
+        "bwd_dh_kernel": 2 * 2 * H * D * N,
+        "tn_kernel": (2 * H * L + 2 * 2 * D * H) * N,
+    }
+    kbytes = {
+        "amil_fwd_fused_bf16_kernel": N * (L * 2 + H * 2 + 2 * D * 2 + 4),     # x read; h, a, b, A_raw written
+        "linear_bf16_kernel": N * (L * 2 + H * 2),                             # x read, h written
+        "gate_bf16_kernel": N * (H * 2 + 2 * D * 2 + 2 * 4),                   # h read; a, b, 2 score parts written
+        "pool_partial_bf16_kernel": N * (H * 2 + 3 * 4),                       # h read; score parts read, A_raw written
+        "dh_bf16_kernel": N * (2 * D * 2 + H * 2 + H * 2 + 2 * D * 2),         # a, b, h read; du, dP written
+        "tn_bf16_kernel": N * (H * 2 + L * 2 + 2 * D * 2 + H * 2),             # du, x, dP, h read
+    }
+    return kflops, kbytes
+
+
+def roofline_of(prof, N, bf16):
+    """`roofline` block for the dominant kernel of a per-kernel profile (see kernel_profile)."""
+    if not prof:
+        return None
+    dom = max(prof.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0]
+    kflops, kbytes = kernel_tables(N)
+    t_us = prof[dom]["avg_us"]
+    traffic, source = recorded_traffic(dom, N, bf16)
+    if bf16 and dom in kbytes:
+        ach = kbytes[dom] / (t_us * 1e-6) / 1e9
+        return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source, "avg_launch_us": t_us,
+                "bytes_per_launch": kbytes[dom]}
+    if dom in kflops:
+        ach = kflops[dom] / (t_us * 1e-6) / 1e12
+        return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
+                "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
+    return None
+
+
+def recorded_traffic(kernel, N, bf16):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command): a recorded figure,
+    not measured by this run -- PMC counters need rocprofv3 around the process -- and only for the workload it was
+    recorded on; null otherwise."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for rec in tj.get("workloads", [tj]):
+            if rec.get("instances") == N and rec.get("dtype", "f32") == ("bf16" if bf16 else "f32") and kernel in rec["kernels"]:
+                return rec["kernels"][kernel]["bytes"], "recorded: " + rec.get("source", "profiles/traffic.json")
+    except Exception:
+        pass
+    return None, None
+
+
+def size_fractions(N, ms, bf16=False):
+    """Whole-step fractions of the two rooflines for one N x 1024 bag processed in `ms`."""
+    tot = flops_per_bag(N)
+    return {"tflops": tot / (ms * 1e-3) / 1e12,
+            "frac_fp32_mfma_peak": tot / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "algorithmic_gbs": bytes_per_bag(N, bf16) / (ms * 1e-3) / 1e9,
+            "frac_hbm_peak": bytes_per_bag(N, bf16) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
 def graph_leg(model, dev, steps, gen):
@@ -201,15 +300,7 @@ def graph_leg(model, dev, steps, gen):
     res = {}
     for n in (1000, 10000):
         x = torch.randn(n, 1024, device=dev, generator=gen)
-        params = list(model.parameters())
-
-        def fn():
-            for p in params:
-                p.grad = None          # gradients are (re)allocated from the graph's private pool: static addresses,
-            hz, S, Yh, _ = model(path_features=x)   # no zero-fill and no accumulate kernels in the captured step
-            loss = loss_fn(hazards=hz, S=S, Y=Y, c=c)
-            loss.backward()
-            return loss
+        fn = make_step(model, x, dev, None, 1)       # the one-call step: 7 kernel nodes, static gradient buffer
 
         gs = GraphedStep(fn)
         try:
@@ -223,10 +314,90 @@ def graph_leg(model, dev, steps, gen):
             dt = time.perf_counter() - t0
         finally:
             gs.close()
-        res[str(n)] = {"bags_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps}
+        res[str(n)] = {"bags_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, **size_fractions(n, 1e3 * dt / steps)}
     for p in model.parameters():
         p.grad = None
     return res
+
+
+def config5_leg(dev, steps, warmup, gen):
+    """BASELINE config 5 on one GPU: bf16 storage, one 100,000 x 1024 bag, path head, train mode -- the HBM-roofline
+    run.  Strictly one bag at a time, plus the two-bags-in-flight rate; `roofline` is for its dominant kernel."""
+    import torch
+    N = 100_000
+    model = build_model(dev, False)
+    x = torch.randn(N, 1024, device=dev, generator=gen).to(torch.bfloat16)
+    step1 = make_step(model, x, dev, None, 1)
+    d1 = time_steps(step1, steps, warmup, 1)
+    ms = 1e3 * d1 / steps
+    prof = kernel_profile(step1, max(5, min(steps, 20)))
+    for p in model.parameters():
+        p.grad = None
+    d2 = time_steps(make_step_inflight(model, x, dev, 1, 2), steps, warmup, 1)
+    out = {"workload": "path_attention_mil small gated K=4, one 100000x1024 bf16 bag, train mode, fwd+nll_surv+bwd",
+           "dtype": "bf16", "bags_per_s": steps / d1, "ms_per_step": ms, "two_bags_in_flight_bags_per_s": steps / d2,
+           "roofline": roofline_of(prof, N, True), "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())},
+           "whole_step": {"algorithmic_gbs": bytes_per_bag(N, True) / (ms * 1e-3) / 1e9,
+                          "frac_hbm_peak": bytes_per_bag(N, True) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "tflops": flops_per_bag(N) / (ms * 1e-3) / 1e12}}
+    del x, model
+    return out
+
+
+def other_configs_leg(dev, steps, warmup, gen):
+    """BASELINE configs 3 and 4 (and 5's multimodal form) on one GPU, ms per fwd + loss + bwd step:
+    radio 4 x 512 x 1024 + omic MaxNet (B = 128, Cox); mm_attention_mil concat / tensor with a 50k fp32 path bag and
+    with a 100k bf16 path bag (+ 4 x 512 radio + omic[80])."""
+    import torch
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_radio, MaxNet, MM_MIL_Attention_fc_surv
+    from multimodalfusion_amd.utils.loss_utils import CoxSurvLoss, NLLSurvLoss
+    MODS = ["T1", "T2", "T1Gd", "FLAIR"]
+    Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
+    nll, cox = NLLSurvLoss(alpha=0.0), CoxSurvLoss()
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
+
+    def timeit(fn):
+        for _ in range(max(3, warmup)):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        return {"ms_per_step": ms, "bags_per_s": 1e3 / ms}
+
+    def stepper(model, kw, loss_of):
+        params = list(model.parameters())
+
+        def fn():
+            for p in params:
+                p.grad = None
+            loss_of(model(**kw)).backward()
+        return fn
+
+    out = {}
+    torch.manual_seed(1)
+    rx = {m: rn(512, 1024) for m in MODS}
+    radio = MIL_Attention_fc_surv_radio(n_classes=4).to(dev).train()
+    out["config3_radio_4x512x1024"] = timeit(stepper(radio, rx, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)))
+    omic = MaxNet(input_dim=36, bag_loss="cox_surv").to(dev).train()
+    ot = torch.rand(128, dtype=torch.float64) * 100
+    oc = (torch.rand(128, device=dev, generator=gen) < 0.5).float()
+    out["config3_omic_maxnet_B128_cox"] = timeit(stepper(omic, {"genomic_features": rn(128, 36)},
+                                                         lambda r: cox(risks=r[0], times=ot, c=oc)))
+    del radio, omic
+    for tag, n, dt in (("config4_mm_50k_f32", 50_000, torch.float32), ("config5_mm_100k_bf16", 100_000, torch.bfloat16)):
+        xp = rn(n, 1024).to(dt)
+        for fusion in ("concat", "tensor"):
+            mm = MM_MIL_Attention_fc_surv(input_dim=80, fusion=fusion, n_classes=4).to(dev).train()
+            kw = dict(rx)
+            kw["path_features"] = xp
+            kw["genomic_features"] = rn(80)
+            out[f"{tag}_{fusion}"] = timeit(stepper(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)))
+            del mm
+        del xp
+    return out
 
 
 def h2d_leg(model, N, dev, steps, warmup, bf16=False):
@@ -242,11 +413,11 @@ def h2d_leg(model, N, dev, steps, warmup, bf16=False):
     loss_fn = NLLSurvLoss(alpha=0.0)
     Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
 
+    flat = torch.empty(sum(p.numel() for p in model.parameters()), device=dev)
+    views = flat_views(model, flat)
+
     def run(x):
-        for p in model.parameters():
-            p.grad = None
-        hz, S, Yh, _ = model(path_features=x)
-        loss_fn(hazards=hz, S=S, Y=Y, c=c).backward()
+        model.nll_step(x, Y, c, alpha=0.0, grad_out=views, accumulate=False)
 
     def batches(n):
         for i in range(n):
@@ -366,7 +537,9 @@ def main():
     if bf16:
         x = x.to(torch.bfloat16)
     inflight = args.inflight if args.inflight > 0 else (2 if bf16 else 3)
-    step = make_step(model, x, dev, flat, world) if inflight == 1 else make_step_inflight(model, x, dev, world, inflight)
+    ag = args.autograd
+    step = (make_step(model, x, dev, flat, world, ag) if inflight == 1
+            else make_step_inflight(model, x, dev, world, inflight, ag))
 
     dt = time_steps(step, args.steps, args.warmup, world)
     ms_per_step = 1e3 * dt / args.steps
@@ -379,7 +552,9 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) {'bf16 ' if bf16 else ''}bag per GPU per step, "
                                f"nll_surv alpha=0, {'eval' if args.eval_mode else 'train (1 dropout mask)'} mode, "
-                               f"fwd+loss+bwd, grads materialised" + (", 1 RCCL all-reduce/step" if world > 1 else "")
+                               f"fwd+loss+bwd, grads materialised, "
+                               + ("autograd surface (model -> loss -> backward)" if ag else "one C-ABI call per bag (model.nll_step)")
+                               + (", 1 RCCL all-reduce/step" if world > 1 else "")
                                + (f", {inflight} bags in flight per GPU on {inflight} HIP streams" if inflight > 1 else ""),
                    "instances_per_bag": N, "parallelism": f"dp{world} (one bag per GPU per step)", "bags_in_flight": inflight},
     }
@@ -387,47 +562,18 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ----
         # rank 0 only: this leg must NOT contain the collective (the other ranks are already at the final barrier)
-        local_step = make_step(model, x, dev, flat, 1)
+        local_step = make_step(model, x, dev, flat, 1, ag)
         if inflight > 1 and world == 1:      # the strictly sequential figure beside it (same run)
             d1 = time_steps(local_step, args.steps, args.warmup, 1)
             out["one_bag_in_flight"] = {"value": args.steps / d1, "ms_per_step": 1e3 * d1 / args.steps}
+            # SURVEY 8(d) defines the metric as ONE bag per GPU per step: that figure at top level, beside `value`
+            out["value_one_bag_per_step"] = args.steps / d1
+            out["ms_per_step_one_bag"] = 1e3 * d1 / args.steps
         out["step_ms_device"] = step_percentiles(local_step, max(10, min(args.steps, 50)))
         prof = kernel_profile(local_step, max(5, min(args.steps, 20)))
-        dom = max(prof.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0] if prof else None
-        kflops = {
-            "linear_nt_kernel": 2 * 1024 * 256 * N,
-            "gate_fwd_kernel": 2 * 2 * 256 * 256 * N,
-            "bwd_dh_kernel": 2 * 2 * 256 * 256 * N,
-            "tn_kernel": (2 * 256 * 1024 + 2 * 2 * 256 * 256) * N,
-        }
-        # bf16 storage: every kernel is HBM-bound; minimal bytes each kernel must move per launch
-        kbytes = {
-            "amil_fwd_fused_bf16_kernel": N * (1024 * 2 + 256 * 2 + 2 * 256 * 2 + 4),     # x read; h, a, b, A_raw written
-            "linear_bf16_kernel": N * (1024 * 2 + 256 * 2),                    # x read, h written
-            "gate_bf16_kernel": N * (256 * 2 + 2 * 256 * 2 + 2 * 4),           # h read; a, b, 2 score parts written
-            "pool_partial_bf16_kernel": N * (256 * 2 + 3 * 4),                 # h read; score parts read, A_raw written
-            "dh_bf16_kernel": N * (2 * 256 * 2 + 256 * 2 + 256 * 2),           # a, b, h read; du written
-            "tn_bf16_kernel": N * (256 * 2 + 1024 * 2 + 2 * 256 * 2 + 256 * 2),  # du, x, a, b, h read
-        }
-        if bf16 and dom in kbytes:
-            t_us = prof[dom]["avg_us"]
-            ach = kbytes[dom] / (t_us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_us,
-                               "bytes_per_launch": kbytes[dom]}
-        elif dom in kflops:
-            t_us = prof[dom]["avg_us"]
-            ach = kflops[dom] / (t_us * 1e-6) / 1e12
-            traffic = None     # HBM bytes per launch from the committed PMC passes (same workload only)
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if tj.get("instances") == N and dom in tj["kernels"]:
-                    traffic = tj["kernels"][dom]["bytes"]
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
+        rl = roofline_of(prof, N, bf16)
+        if rl is not None:
+            out["roofline"] = rl
         tot = flops_per_bag(N)
         mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         out["whole_step"] = {"tflops": tot / (ms_per_step * 1e-3) / 1e12,
@@ -436,18 +582,32 @@ def main():
                              "algorithmic_gbs": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9,
                              "frac_hbm_peak": bytes_per_bag(N, bf16) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         out["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}
-        if args.extra_sizes and world == 1:
+        for p in model.parameters():
+            p.grad = None
+        if world == 1 and not ag:          # the same bag through the autograd surface, one at a time
+            da = time_steps(make_step(model, x, dev, None, 1, True), args.steps, args.warmup, 1)
+            out["autograd_surface"] = {"one_bag_value": args.steps / da, "ms_per_step": 1e3 * da / args.steps}
+            for p in model.parameters():
+                p.grad = None
+        if args.extras and world == 1:
+            # north_star's other bag sizes: eager (host-bound: Python + autograd + ~12 launches) and as one hipGraph
             extra = {}
             for n2 in (1000, 10000):
                 x2 = torch.randn(n2, 1024, device=dev, generator=g)
-                st2 = make_step(model, x2, dev, None, 1)
-                d2 = time_steps(st2, args.steps, args.warmup, 1)
-                extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": 1e3 * d2 / args.steps}
+                d2 = time_steps(make_step(model, x2, dev, None, 1), args.steps, args.warmup, 1)
+                ms2 = 1e3 * d2 / args.steps
+                d3 = time_steps(make_step(model, x2, dev, None, 1, True), args.steps, args.warmup, 1)
+                for p in model.parameters():
+                    p.grad = None
+                extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": ms2, **size_fractions(n2, ms2),
+                                  "autograd_surface_ms_per_step": 1e3 * d3 / args.steps}
             out["other_sizes"] = extra
-        if args.graph and world == 1:
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
-        if args.h2d and world == 1:
-            out["pcie_inclusive"] = h2d_leg(model, N, dev, args.steps, args.warmup, bf16)
+            if not bf16 and N == 50000:
+                out["config5_bf16_100k"] = config5_leg(dev, max(10, args.steps), args.warmup, g)
+                out["other_configs"] = other_configs_leg(dev, max(10, min(args.steps, 30)), args.warmup, g)
+        if args.h2d and args.extras and world == 1:
+            out["pcie_inclusive"] = h2d_leg(model, N, dev, max(10, min(args.steps, 30)), args.warmup, bf16)
         if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

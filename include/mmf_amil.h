@@ -104,6 +104,49 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* desc, const uint16_t* x, void* w
                            const mmf_amil_grads* grads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Attention stack + classifier / hazard head in one call, and the whole training step of one bag in one call.
+ *   The path head's forward is stack -> classifier -> sigmoid / cumprod / argmax (models/model_attention_mil_path.py:
+ *   52-61); the training loop then applies nll_surv and calls backward (utils/core_utils.py:200-243).  After the
+ *   pooling kernel these are single-workgroup launches of a few microseconds each; here they run as the tail of the
+ *   pooling merge kernel (its last workgroup), so a bag costs 7 launches instead of 12 -- what matters for 1k-10k bags.
+ *   x_bf16 != 0: x is a bf16 bag (uint16_t bits) and the bf16-storage kernels run (see above).
+ *   workspace: mmf_amil_workspace_bytes / mmf_amil_bf16_workspace_bytes of the same shape.
+ * mmf_amil_head_forward: stack + head; M [H], A_raw [N] and the head outputs are written; backward as usual
+ *   (mmf_surv_head_backward, then mmf_amil[_bf16]_backward with the same workspace).
+ * mmf_amil_nll_step: forward + head + nll_surv + backward.  Writes the head outputs, loss (unscaled) and A_raw, and the
+ *   gradients of loss * loss_scale w.r.t. every parameter: grads (attention stack) and target->dWk / dbk
+ *   (classifier), overwritten, or ADDED to what the buffers hold when target->accumulate != 0 (gradient accumulation
+ *   over the `gc` bags of a window, utils/core_utils.py:242-247, with loss_scale = 1 / gc).  grads->dx must be NULL.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mmf_surv_head {
+  const float* Wk;      /* [K x H] classifier.weight */
+  const float* bk;      /* [K] */
+  int32_t K;            /* <= 32 */
+  float* logits;        /* [K] out */
+  float* hazards;       /* [K] out */
+  float* S;             /* [K] out */
+  int64_t* Y_hat;       /* [1] out */
+  float* risk;          /* [1] out = -sum_k S_k (what the loop logs, utils/core_utils.py:207), or NULL */
+} mmf_surv_head;
+
+typedef struct mmf_nll_target {
+  const int64_t* Y;     /* [1] device: discrete time bin */
+  const float* c;       /* [1] device: censorship */
+  float alpha, eps;     /* NLLSurvLoss(alpha), eps = 1e-7 */
+  float loss_scale;     /* gradients are those of loss * loss_scale */
+  float* loss;          /* [1] out, unscaled */
+  float* dWk;           /* [K x H] */
+  float* dbk;           /* [K] */
+  int32_t accumulate;   /* 0: every gradient buffer is overwritten; 1: added to */
+} mmf_nll_target;
+
+int mmf_amil_head_forward(const mmf_amil_desc* desc, const void* x, int32_t x_bf16, void* workspace, size_t workspace_bytes,
+                          const mmf_surv_head* head, float* M, float* A_raw, void* stream);
+int mmf_amil_nll_step(const mmf_amil_desc* desc, const void* x, int32_t x_bf16, void* workspace, size_t workspace_bytes,
+                      const mmf_surv_head* head, const mmf_nll_target* target, float* A_raw,
+                      const mmf_amil_grads* grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Forward-only variants for the inference consumers of the path -- embedding export
  * (pre_trained_feature.py:116-162: model(..., return_features=True) under no_grad), per-patient inference and
  * attention heat-map scoring (utils/heatmap_utils.py:111-150,249-275: A_raw per bag / per 512-patch batch).

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -35,6 +35,19 @@ class AmilGrads(C.Structure):
         ("dWb", C.c_void_p), ("dbb", C.c_void_p), ("dWc", C.c_void_p), ("dbc", C.c_void_p),
         ("dx", C.c_void_p),
     ]
+
+
+class SurvHead(C.Structure):
+    """struct mmf_surv_head (include/mmf_amil.h)."""
+    _fields_ = [("Wk", C.c_void_p), ("bk", C.c_void_p), ("K", C.c_int32), ("logits", C.c_void_p),
+                ("hazards", C.c_void_p), ("S", C.c_void_p), ("Y_hat", C.c_void_p), ("risk", C.c_void_p)]
+
+
+class NllTarget(C.Structure):
+    """struct mmf_nll_target (include/mmf_amil.h)."""
+    _fields_ = [("Y", C.c_void_p), ("c", C.c_void_p), ("alpha", C.c_float), ("eps", C.c_float),
+                ("loss_scale", C.c_float), ("loss", C.c_void_p), ("dWk", C.c_void_p), ("dbk", C.c_void_p),
+                ("accumulate", C.c_int32)]
 
 
 class XReduceIO(C.Structure):
@@ -61,6 +74,10 @@ SYMBOLS = {
     "mmf_amil_bf16_backward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(AmilGrads), C.c_void_p]),
+    "mmf_amil_head_forward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                        C.POINTER(SurvHead), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_amil_nll_step": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
+                                    C.POINTER(SurvHead), C.POINTER(NllTarget), C.c_void_p, C.POINTER(AmilGrads), C.c_void_p]),
     "mmf_amil_infer_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mmf_amil_infer": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -105,10 +105,14 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
       dsr[i] = ok ? ds_lds[rl] : 0.f;
     }
   }
+  // k order of the gated contraction: chunk 2j = d pre-tanh, chunk 2j + 1 = d pre-sigmoid of the SAME 32 attention
+  // dims (LoadWab_M walks [Wa ; Wb] in the same order; a sum does not care).  Both halves are built from the same
+  // a, b, Wc values, so the odd chunk issues no loads and reuses the even chunk's registers: a and b cross HBM once
+  // per tile instead of twice (PMC, 50k bag: 369 MB per launch with the [all of Wa | all of Wb] order).
   __device__ inline void load(int kt) {
-    const int nka = g.D / KC;
-    part = kt >= nka ? 1 : 0;
-    d0 = (kt - part * nka) * KC;
+    part = g.gated ? (kt & 1) : 0;
+    d0 = (g.gated ? (kt >> 1) : kt) * KC;
+    if (part) return;
     const unsigned soff = (unsigned)d0 * 4u;
     wc4 = bld4(rwc, 16u * (tid & 7), soff);
 #pragma unroll
@@ -158,17 +162,19 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   }
 };
 
-// B[k][n] = stacked [Wa ; Wb] rows (k < D -> Wa[k], else Wb[k-D]); m-contiguous image
+// B[k][n] = rows of Wa / Wb in LoadP_K's k order (gated: chunk 2j = Wa rows 32j.., chunk 2j + 1 = Wb rows 32j..);
+// m-contiguous image
 template <int ROWS, int NT>
 struct LoadWab_M {
   using Map = MMap<ROWS, NT>;
   rsrc_t ra, rb;
+  bool gated;
   int D, tid;
   unsigned hb;
   unsigned voff[Map::NV];
   float4 r[Map::NV];
-  __device__ inline void init(const float* wa, const float* wb, int H, int D_, int col0) {
-    D = D_; tid = threadIdx.x; hb = (unsigned)H * 4u;
+  __device__ inline void init(const float* wa, const float* wb, int H, int D_, int col0, bool gated_) {
+    D = D_; tid = threadIdx.x; hb = (unsigned)H * 4u; gated = gated_ && wb != nullptr;
     ra = make_rsrc(wa, (unsigned)D * hb);
     rb = make_rsrc(wb ? wb : wa, (unsigned)D * hb);
 #pragma unroll
@@ -177,10 +183,9 @@ struct LoadWab_M {
       voff[i] = (Map::valid(tid, i) && c < H) ? (unsigned)Map::krow(tid, i) * hb + (unsigned)c * 4u : OOB;
     }
   }
-  __device__ inline void load(int kt) {     // a chunk never straddles the Wa | Wb boundary (D % KC == 0)
-    const int k0 = kt * KC;
-    const bool second = k0 >= D;
-    const unsigned soff = (unsigned)(k0 - (second ? D : 0)) * hb;
+  __device__ inline void load(int kt) {
+    const bool second = gated && (kt & 1);
+    const unsigned soff = (unsigned)((gated ? (kt >> 1) : kt) * KC) * hb;
 #pragma unroll
     for (int i = 0; i < Map::NV; ++i) r[i] = bld4(second ? rb : ra, voff[i], soff);
   }
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
     la.init(p.g, row0, (int)p.N);
   }
   LoadWab_M<T::BN, T::NT> lb;
-  lb.init(p.Wa, p.Wb, p.H, p.g.D, col0);
+  lb.init(p.Wa, p.Wb, p.H, p.g.D, col0, p.g.gated != 0);
   f32x16 acc[T::MB][T::NB];
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
   MMF_KSTAMP(k1);
@@ -304,6 +309,49 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
       const int col = col0 + epilogue_col<T>(nb);
       dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
     }
+    if (p.relu_bits) {
+      // relu'(u) . keep comes as one bit per element from the forward (LinearParams::relu_bits): 16 ballot words per
+      // 32x32 block -- lane i < 16 loads word i (one 128-byte request per block), v_readlane moves a word into an
+      // SGPR pair and that pair IS the lane mask of a v_cndmask.  h is not read again (51 MB per 50k bag, in the one
+      // phase of the kernel where every CU sits on HBM at the same time).
+      const int cbn = p.H >> 5;
+      typedef unsigned long long u64;
+      u64 mv[2];
+      auto fetch_bits = [&](int b, int s) {
+        const int mb = b / T::NB, nb = b % T::NB;
+        const int64_t rb = ((int64_t)row0 >> 5) + wm * T::MB + mb;
+        const int cb = (col0 >> 5) + wn * T::NB + nb;
+        const bool ok = rb * 32 < p.N && cb < cbn && lane < 16;
+        mv[s] = ok ? p.relu_bits[((size_t)rb * cbn + cb) * 16 + lane] : 0ull;
+      };
+      fetch_bits(0, 0);
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int mb = b / T::NB, nb = b % T::NB, s = b & 1;
+        if (b + 1 < NBLK) fetch_bits(b + 1, s ^ 1);
+        float4 v[4];
+        transpose_block(acc[mb][nb], blk, lane, v);
+        const int r = (wm * T::MB + mb) * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
+        if (col >= p.H) continue;
+        const float4 dm = dm4[nb];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int row = row0 + r + 8 * t;
+          const float pi = FUSED ? p_l[r + 8 * t] : p.p[row < p.N ? row : (int)p.N - 1];
+          const float raw[4] = {(v[t].x + pi * dm.x) * p.scale_h, (v[t].y + pi * dm.y) * p.scale_h,
+                                (v[t].z + pi * dm.z) * p.scale_h, (v[t].w + pi * dm.w) * p.scale_h};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)mv[s], 4 * t + e);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mv[s] >> 32), 4 * t + e);
+            const u64 m = ((u64)hi << 32) | lo;
+            asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o[e]) : "v"(raw[e]), "s"(m));
+          }
+          if (row < p.N) st4(p.du + (size_t)row * p.H + col, make_float4(o[0], o[1], o[2], o[3]));
+        }
+      }
+    } else {
     float4 hv[2][4];
     float pv[2][4];
     auto fetch = [&](int b, int s) {
@@ -340,6 +388,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
         du.w = h4.w > 0.f ? (v[t].w + pi * dm.w) * p.scale_h : 0.f;
         st4(p.du + (size_t)row * p.H + col, du);
       }
+    }
     }
   }
 #ifdef MMF_STAMPS
@@ -672,7 +721,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams p) {
       acc = wave_sum(acc);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
       __syncthreads();
-      if (threadIdx.x == 0) s.out[e] = red[0] + red[1] + red[2] + red[3];
+      if (threadIdx.x == 0) s.out[e] = (p.accumulate ? s.out[e] : 0.f) + (red[0] + red[1] + red[2] + red[3]);
       __syncthreads();
     }
     return;
@@ -704,7 +753,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams p) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += part[g][threadIdx.x];
       const int c = (b - s.block_begin) * 64 + threadIdx.x;
-      if (c < s.len) s.out[c] = t;
+      if (c < s.len) s.out[c] = (p.accumulate ? s.out[c] : 0.f) + t;
     }
     return;
   }
@@ -726,12 +775,13 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams p) {
       float4 v = ld4(in + (size_t)k * s.stride);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    if (p.accumulate) { const float4 o = ld4(s.out + j); acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
     st4(s.out + j, acc);
   } else {
     for (int e = j; e < j + 4 && e < s.len; ++e) {
       float acc = 0.f;
       for (int k = 0; k < s.nsplit; ++k) acc += s.in[(size_t)k * s.stride + e];
-      s.out[e] = acc;
+      s.out[e] = (p.accumulate ? s.out[e] : 0.f) + acc;
     }
   }
 }

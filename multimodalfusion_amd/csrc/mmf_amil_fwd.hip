@@ -53,14 +53,16 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
     const int col = col0 + epilogue_col<T>(nb);
     bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
   }
+  const int lane = threadIdx.x & 63;
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
     const int col = col0 + c;
-    if (col >= p.N) return;                  // N % 4 == 0: a float4 never straddles the edge
+    const bool col_ok = col < p.N;           // N % 4 == 0: a float4 never straddles the edge
     const float4 b4 = bias4[nb];
+    unsigned long long mine = 0ull;          // lane 4 t + e keeps ballot (t, e) of this block (LinearParams::relu_bits)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int row = row0 + r + 8 * t;
-      if (row >= p.M) continue;
+      const bool ok = col_ok && row < p.M;
       float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
       const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
 #pragma unroll
@@ -69,10 +71,21 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
         else if constexpr (ACT < 0) y[e] = apply_act(y[e], p.act);
         if constexpr (DROP) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
+      if (p.relu_bits) {                     // wave-uniform; the ballots are taken by every lane, valid or not
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned long long bal = __ballot(ok && y[e] > 0.f);
+          if (lane == 4 * t + e) mine = bal;
+        }
+      }
 #ifdef MMF_DIAG_NOSTORE       /* diagnostic build: everything but the global stores (results are wrong) */
       if (y[0] == 1.2345e30f)
 #endif
-      st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
+      if (ok) st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
+    }
+    if (p.relu_bits && lane < 16) {
+      const size_t rb = (size_t)(row0 + r - (lane >> 3)) >> 5, cb = (size_t)(col0 + c - 4 * (lane & 7)) >> 5;
+      if ((int64_t)rb * 32 < p.M && (int)(cb * 32) < p.N) p.relu_bits[(rb * (size_t)(p.N >> 5) + cb) * 16 + lane] = mine;
     }
   });
 }
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   __shared__ float red[256];
   __shared__ __align__(16) float vred[1024];   // RG * VPR == 256 float4 slots
   const int tid = threadIdx.x, g = blockIdx.x;
+  if (g == 0 && tid == 0 && p.zero_word) *p.zero_word = 0u;
   const int64_t r0 = (int64_t)g * p.rows_per_group;
   const int64_t r1 = r0 + p.rows_per_group < p.N ? r0 + p.rows_per_group : p.N;
   const int nrows = r1 > r0 ? (int)(r1 - r0) : 0;
@@ -344,11 +358,130 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   }
 }
 
+// Tail of K-merge (HeadTail): 1024 threads of the last workgroup.  M is read with agent-scope atomic loads: the
+// other workgroups published their columns with a fence before taking their ticket.  Everything the tail needs that
+// does not depend on M (classifier rows / columns, bias, label, censorship) is requested by EVERY workgroup at kernel
+// entry (TailPre): the tail is a chain of dependent steps, and each global load left in it costs a memory round trip.
+struct TailPre {
+  float wk_row[16];   // wave k < K: Wk[k][lane + 64 j]        (H <= 1024)
+  float wk_col[8];    // thread c < H: Wk[k][c], k < min(K, 8)
+  float bk;           // lane 0 of wave k
+  float c;            // thread 0
+  long long y;        // thread 0
+};
+__device__ inline void tail_preload(const PoolParams& p, TailPre& r) {
+  const HeadTail& t = p.tail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r.wk_row[j] = (wave < t.K && lane + 64 * j < p.H) ? t.Wk[(size_t)wave * p.H + lane + 64 * j] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.wk_col[k] = (k < t.K && tid < p.H) ? t.Wk[(size_t)k * p.H + tid] : 0.f;
+  r.bk = (wave < t.K && lane == 0) ? t.bk[wave] : 0.f;
+  r.c = (tid == 0 && t.c) ? t.c[0] : 0.f;
+  r.y = (tid == 0 && t.Y) ? (long long)t.Y[0] : 0;
+}
+__device__ inline void head_tail(const PoolParams& p, const TailPre& r, float* sm /* 1024 + 160 floats */) {
+  const HeadTail& t = p.tail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, K = t.K;
+  float* Ml = sm;                 // [H]
+  float* z = sm + 1024;           // [K] logits, then dz
+  float *hz = z + 32, *S = z + 64, *gH = z + 96, *gS = z + 128;   // K <= 32; in LDS: indexed arrays in registers would go to scratch
+  for (int c = tid; c < H; c += 1024) Ml[c] = __hip_atomic_load(p.M + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (wave < K) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (lane + 64 * j < H) acc += Ml[lane + 64 * j] * r.wk_row[j];
+    acc = wave_sum(acc);
+    if (lane == 0) z[wave] = acc + r.bk;
+  }
+  for (int k = 16 + wave; k < K; k += 16) {          // K > 16: the rows that were not preloaded
+    float acc = 0.f;
+    for (int c = lane; c < H; c += 64) acc += Ml[c] * t.Wk[(size_t)k * H + c];
+    acc = wave_sum(acc);
+    if (lane == 0) z[k] = acc + t.bk[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // forward (surv_head_fwd_kernel) ...
+    float run = 1.f, best = -INFINITY, ssum = 0.f;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+      const float zz = z[k];
+      hz[k] = 1.0f / (1.0f + expf(-zz));
+      run *= (1.0f - hz[k]);
+      S[k] = run;
+      ssum += run;
+      t.logits[k] = zz; t.hazards[k] = hz[k]; t.S[k] = run;
+      if (zz > best) { best = zz; arg = k; }
+    }
+    t.Y_hat[0] = arg;
+    if (t.risk) t.risk[0] = -ssum;
+    if (t.Y) {
+      // ... nll_surv for the one sample (nll_surv_kernel) ...
+      for (int k = 0; k < K; ++k) { gH[k] = 0.f; gS[k] = 0.f; }
+      const long long y64 = r.y;
+      float l;
+      if (y64 < 0 || y64 >= K) {
+        l = __builtin_nanf("");
+      } else {
+        const int y = (int)y64;
+        const float c = r.c;
+        const float sp_y = y == 0 ? 1.0f : S[y - 1];
+        const float hy = hz[y];
+        const float unc = -(1.f - c) * (logf(fmaxf(sp_y, t.eps)) + logf(fmaxf(hy, t.eps)));
+        if (y > 0 && sp_y >= t.eps) gS[y - 1] += -(1.f - c) / sp_y;
+        if (hy >= t.eps) gH[y] += -(1.f - c) / hy;
+        const float sp_y1 = S[y];
+        const float cen = -c * logf(fmaxf(sp_y1, t.eps));
+        if (sp_y1 >= t.eps) gS[y] += -(1.f - t.alpha) * c / sp_y1;
+        l = (1.f - t.alpha) * (cen + unc) + t.alpha * unc;
+      }
+      t.loss[0] = l;
+      // ... and the head's backward (surv_head_bwd_kernel): dz_t = (gH_t - sum_{j>=t} gS_j prod_{u<=j,u!=t}(1-h_u)) h_t (1-h_t)
+      for (int k = 0; k < K; ++k) {
+        float g = gH[k];
+        for (int j = k; j < K; ++j) {
+          float prod = 1.f;
+          for (int u = 0; u <= j; ++u)
+            if (u != k) prod *= (1.0f - hz[u]);
+          g -= gS[j] * prod;
+        }
+        z[k] = g * hz[k] * (1.0f - hz[k]) * t.loss_scale;
+      }
+    }
+  }
+  if (!t.Y) return;
+  __syncthreads();
+  for (int c = tid; c < H; c += 1024) {
+    float acc = 0.f;
+    if (c == tid) {                   // the preloaded columns (every c when H <= 1024)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < K) acc += z[k] * r.wk_col[k];
+      for (int k = 8; k < K; ++k) acc += z[k] * t.Wk[(size_t)k * H + c];
+    } else {
+      for (int k = 0; k < K; ++k) acc += z[k] * t.Wk[(size_t)k * H + c];
+    }
+    t.dM[c] = acc;
+    for (int k = 0; k < K; ++k) {
+      float* o = t.dWk + (size_t)k * H + c;
+      const float v = z[k] * Ml[c];
+      *o = t.accumulate ? *o + v : v;
+    }
+  }
+  if (tid < K) t.dbk[tid] = t.accumulate ? t.dbk[tid] + z[tid] : z[tid];
+}
+
 // H/32 workgroups of 1024 threads: merge the per-group partials.
 // Group weights exp(m_g - m) are computed once into LDS; the column sums then run as independent, unrolled
 // loads (the first version's serial dependent loop over groups cost 115 us).
 constexpr int MERGE_MAX_GROUPS = 4096;
 __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
+  TailPre pre;
+  if (p.tail.Wk) tail_preload(p, pre);
   __shared__ float wl[MERGE_MAX_GROUPS];
   __shared__ float red[32];
   __shared__ float colred[1024];
@@ -397,6 +530,19 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
     p.M[c] = s / l;
   }
   if (blockIdx.x == 0 && tid == 0) { p.stats[0] = m; p.stats[1] = l; }
+  if (p.tail.Wk) {
+    __shared__ unsigned last;
+    __threadfence();                       // this workgroup's columns of M are visible before its ticket is
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(p.tail.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      __shared__ float tail_sm[1024 + 160];
+      head_tail(p, pre, tail_sm);
+      if (tid == 0) *p.tail.ticket = 0u;
+    }
+  }
 }
 
 // =============================================================================================
@@ -518,6 +664,7 @@ int launch_pool(PoolParams p, hipStream_t st) {
 
 int launch_pool_merge(PoolParams p, hipStream_t st) {
   if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || p.H % 32 != 0) return MMF_ERR_SHAPE;
+  if (p.tail.Wk && (p.tail.K < 1 || p.tail.K > 32 || !p.tail.ticket)) return MMF_ERR_SHAPE;
   { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(p.H / 32), dim3(1024), 0, st, p); }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }

@@ -81,6 +81,9 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 constexpr int PREP_GROUPS = 512;
 
 struct AmilWs {
+  unsigned* ticket;                  // K-merge's "last workgroup" counter (head tail)
+  float *M_step, *dM_step;           // [H] each: pooled embedding and its gradient inside mmf_amil_nll_step
+  unsigned long long* relu_bits;     // [ceil(N/32)][H/32][16]: h > 0 per element (LinearParams::relu_bits)
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
   int parts, groups, splits, k_per_split, mstk, tile;
@@ -129,6 +132,9 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
     if (kpg < KC) kpg = KC;
     w.splits_g = sg; w.k_per_split_g = kpg;
   }
+  w.ticket = reinterpret_cast<unsigned*>(take(4));
+  w.M_step = take(H);
+  w.dM_step = take(H);
   w.h = take((size_t)N * H);
   w.s_part = take((size_t)w.parts * N);
   w.partials = take((size_t)w.groups * (2 + H));
@@ -137,6 +143,7 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
     w.bytes = off;
     return w;
   }
+  w.relu_bits = reinterpret_cast<unsigned long long*>(take((size_t)((N + 31) / 32) * (H / 32) * 16 * 2));
   w.a = take((size_t)N * D);
   w.b = take(gated ? (size_t)N * D : 0);
   w.p = take((size_t)N);
@@ -169,6 +176,8 @@ static int check_desc(const mmf_amil_desc* d, int elem_bytes = 4) {
 
 // ---- bf16-storage path (mmf_bf16.h) ----------------------------------------------------------
 struct AmilWsBf {
+  unsigned* ticket;
+  float *M_step, *dM_step;
   bf16_t *w1, *wab, *wabT, *h, *a, *b, *du, *dP;
   float *s_part, *partials, *stats, *p, *ds, *dbc_part, *dwc_part;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab;
@@ -196,6 +205,9 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   const int64_t kps = (N + w.splits - 1) / w.splits;
   w.k_per_split = (int)((kps + TNB_KCH - 1) / TNB_KCH * TNB_KCH);
   w.dbc_cap = dh_bf16_row_tiles(N);
+  w.ticket = reinterpret_cast<unsigned*>(take32(4));
+  w.M_step = take32(H);
+  w.dM_step = take32(H);
   w.w1 = take16((size_t)H * L);
   w.wab = take16((size_t)w.mstk * H);
   w.wabT = take16((size_t)H * w.mstk);
@@ -238,7 +250,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 6; }
+int mmf_abi_version(void) { return 7; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -258,13 +270,14 @@ size_t mmf_amil_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int3
 }
 
 static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
-                             float* M, float* A_raw, void* stream, bool infer) {
+                             float* M, float* A_raw, void* stream, bool infer, const HeadTail* tail = nullptr) {
   if (int e = check_desc(d)) return e;
-  if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
+  if (!x || !workspace || !A_raw) return MMF_ERR_ARG;
   if (!aligned16(x) || !aligned16(workspace) || !aligned16(d->W1) || !aligned16(d->Wa) || (d->gated && !aligned16(d->Wb)))
     return MMF_ERR_ALIGN;
   AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  if (!M) M = w.M_step;
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceScope ts(d->trace);
   const uint32_t* const seed_dev = d->seed_dev;
@@ -274,6 +287,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   lp.w = d->W1; lp.bias = d->b1; lp.y = w.h;
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
   lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
+  lp.relu_bits = infer ? nullptr : w.relu_bits;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
@@ -286,6 +300,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   PoolParams pp{};
   pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = w.h; pp.N = d->N; pp.H = d->H;
   pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
+  if (tail) { pp.tail = *tail; pp.tail.ticket = w.ticket; pp.tail.dM = w.dM_step; pp.zero_word = w.ticket; }
   return launch_pool(pp, st);
 }
 
@@ -304,17 +319,19 @@ int mmf_amil_infer(const mmf_amil_desc* d, const float* x, void* workspace, size
   return amil_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, true);
 }
 
-int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
-                      const float* M, const float* A_raw, const float* dM, const float* gA,
-                      const mmf_amil_grads* g, void* stream) {
+static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                              const float* M, const float* A_raw, const float* dM, const float* gA,
+                              const mmf_amil_grads* g, void* stream, int accumulate) {
   if (int e = check_desc(d)) return e;
-  if (!x || !workspace || !M || !A_raw || !dM || !g) return MMF_ERR_ARG;
+  if (!x || !workspace || !A_raw || !g) return MMF_ERR_ARG;
   if (!g->dW1 || !g->db1 || !g->dWa || !g->dba || !g->dWc || !g->dbc) return MMF_ERR_ARG;
   if (d->gated && (!g->dWb || !g->dbb)) return MMF_ERR_ARG;
   if (!aligned16(g->dW1) || !aligned16(g->dWa) || (d->gated && !aligned16(g->dWb)) || (g->dx && !aligned16(g->dx)))
     return MMF_ERR_ALIGN;
   AmilWs w = carve(workspace, d->N, d->L, d->H, d->D, d->gated);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  if (!M) M = w.M_step;          // inside mmf_amil_nll_step the pooled embedding and its gradient live in the workspace
+  if (!dM) dM = w.dM_step;
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceScope ts(d->trace);
   const uint32_t* const seed_dev = d->seed_dev;
@@ -325,6 +342,7 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
 
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
+  dp.relu_bits = w.relu_bits;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
@@ -379,7 +397,15 @@ int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, s
   seg(w.cs_wc, g->dWc, d->D, w.splits_g, d->D);
   seg(w.dbc_part, g->dbc, 1, dbc_groups, 1);
   rp.nseg = n;
+  rp.accumulate = accumulate;
   return launch_reduce(rp, st);
+}
+
+int mmf_amil_backward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                      const float* M, const float* A_raw, const float* dM, const float* gA,
+                      const mmf_amil_grads* g, void* stream) {
+  if (!M || !dM) return MMF_ERR_ARG;
+  return amil_backward_impl(d, x, workspace, workspace_bytes, M, A_raw, dM, gA, g, stream, 0);
 }
 
 size_t mmf_amil_bf16_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D, int32_t gated) {
@@ -388,18 +414,22 @@ size_t mmf_amil_bf16_workspace_bytes(int64_t N, int32_t L, int32_t H, int32_t D,
 }
 
 static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
-                                  float* M, float* A_raw, void* stream, bool infer) {
+                                  float* M, float* A_raw, void* stream, bool infer, const HeadTail* tail = nullptr) {
   if (int e = check_desc_bf16(d)) return e;
-  if (!x || !workspace || !M || !A_raw) return MMF_ERR_ARG;
+  if (!x || !workspace || !A_raw) return MMF_ERR_ARG;
   if (!aligned16(x) || !aligned16(workspace)) return MMF_ERR_ALIGN;
   AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated, infer);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  if (!M) M = w.M_step;
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceScope ts(d->trace);
   const uint32_t* const seed_dev = d->seed_dev;
+  HeadTail tl{};
+  if (tail) { tl = *tail; tl.ticket = w.ticket; tl.dM = w.dM_step; }
 
   CvtParams cp{};
   cp.nseg = 0;
+  cp.zero_word = tail ? w.ticket : nullptr;
   auto cvt = [&](const float* src, bf16_t* dst, int rows, int cols, int dst_ld, int c0, int transpose) {
     cp.seg[cp.nseg++] = CvtSeg{src, dst, rows, cols, dst_ld, c0, transpose, 0};
   };
@@ -427,6 +457,7 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     PoolParams pm{};
     pm.N = d->N; pm.H = d->H; pm.partials = w.partials; pm.M = M; pm.stats = w.stats;
     pm.n_groups = fused_fwd_tiles(d->N);
+    pm.tail = tl;
     return launch_pool_merge(pm, st);
   }
 
@@ -448,6 +479,7 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   PoolParams& pp = pb.base;
   pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = nullptr; pp.N = d->N; pp.H = d->H;
   pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
+  pp.tail = tl;
   pb.h = w.h;
   return launch_pool_bf16(pb, st);
 }
@@ -467,17 +499,19 @@ int mmf_amil_bf16_infer(const mmf_amil_desc* d, const uint16_t* x, void* workspa
   return amil_bf16_forward_impl(d, x, workspace, workspace_bytes, M, A_raw, stream, true);
 }
 
-int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
-                           const float* M, const float* A_raw, const float* dM, const float* gA,
-                           const mmf_amil_grads* g, void* stream) {
+static int amil_bf16_backward_impl(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                                   const float* M, const float* A_raw, const float* dM, const float* gA,
+                                   const mmf_amil_grads* g, void* stream, int accumulate) {
   if (int e = check_desc_bf16(d)) return e;
-  if (!x || !workspace || !M || !A_raw || !dM || !g) return MMF_ERR_ARG;
+  if (!x || !workspace || !A_raw || !g) return MMF_ERR_ARG;
   if (!g->dW1 || !g->db1 || !g->dWa || !g->dba || !g->dWc || !g->dbc) return MMF_ERR_ARG;
   if (d->gated && (!g->dWb || !g->dbb)) return MMF_ERR_ARG;
   if (g->dx) return MMF_ERR_ARG;     // the bf16 bag is a leaf: no input gradient on this path
   if (!aligned16(g->dW1) || !aligned16(g->dWa) || (d->gated && !aligned16(g->dWb))) return MMF_ERR_ALIGN;
   AmilWsBf w = carve_bf16(workspace, d->N, d->L, d->H, d->D, d->gated);
   if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  if (!M) M = w.M_step;
+  if (!dM) dM = w.dM_step;
   hipStream_t st = static_cast<hipStream_t>(stream);
   TraceScope ts(d->trace);
   const uint32_t* const seed_dev = d->seed_dev;
@@ -522,7 +556,57 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* work
   seg(w.dwc_part, g->dWc, d->D, dh_bf16_tiles_used(d->N, ntn), d->D);
   seg(w.dbc_part, g->dbc, 1, dh_bf16_tiles_used(d->N, ntn), 1);
   rp.nseg = n;
+  rp.accumulate = accumulate;
   return launch_reduce(rp, st);
+}
+
+int mmf_amil_bf16_backward(const mmf_amil_desc* d, const uint16_t* x, void* workspace, size_t workspace_bytes,
+                           const float* M, const float* A_raw, const float* dM, const float* gA,
+                           const mmf_amil_grads* g, void* stream) {
+  if (!M || !dM) return MMF_ERR_ARG;
+  return amil_bf16_backward_impl(d, x, workspace, workspace_bytes, M, A_raw, dM, gA, g, stream, 0);
+}
+
+// ---- attention stack + hazard head [+ nll_surv + the whole backward] in one call ------------------------------
+static int head_tail_of(const mmf_surv_head* h, const mmf_nll_target* t, int H, HeadTail& tl) {
+  if (!h || !h->Wk || !h->bk || !h->logits || !h->hazards || !h->S || !h->Y_hat) return MMF_ERR_ARG;
+  if (h->K < 1 || h->K > 32) return MMF_ERR_SHAPE;
+  tl = HeadTail{};
+  tl.Wk = h->Wk; tl.bk = h->bk; tl.K = h->K;
+  tl.logits = h->logits; tl.hazards = h->hazards; tl.S = h->S; tl.Y_hat = h->Y_hat; tl.risk = h->risk;
+  if (t) {
+    if (!t->Y || !t->c || !t->loss || !t->dWk || !t->dbk) return MMF_ERR_ARG;
+    tl.Y = t->Y; tl.c = t->c; tl.alpha = t->alpha; tl.eps = t->eps; tl.loss_scale = t->loss_scale;
+    tl.loss = t->loss; tl.dWk = t->dWk; tl.dbk = t->dbk; tl.accumulate = t->accumulate;
+  }
+  (void)H;
+  return MMF_OK;
+}
+
+int mmf_amil_head_forward(const mmf_amil_desc* d, const void* x, int32_t x_bf16, void* workspace, size_t workspace_bytes,
+                          const mmf_surv_head* head, float* M, float* A_raw, void* stream) {
+  if (!d || !M) return MMF_ERR_ARG;
+  HeadTail tl;
+  if (int e = head_tail_of(head, nullptr, d->H, tl)) return e;
+  return x_bf16 ? amil_bf16_forward_impl(d, static_cast<const uint16_t*>(x), workspace, workspace_bytes, M, A_raw, stream, false, &tl)
+                : amil_forward_impl(d, static_cast<const float*>(x), workspace, workspace_bytes, M, A_raw, stream, false, &tl);
+}
+
+int mmf_amil_nll_step(const mmf_amil_desc* d, const void* x, int32_t x_bf16, void* workspace, size_t workspace_bytes,
+                      const mmf_surv_head* head, const mmf_nll_target* target, float* A_raw,
+                      const mmf_amil_grads* grads, void* stream) {
+  if (!d || !target || !grads) return MMF_ERR_ARG;
+  HeadTail tl;
+  if (int e = head_tail_of(head, target, d->H, tl)) return e;
+  const int acc = target->accumulate ? 1 : 0;
+  if (x_bf16) {
+    const uint16_t* xb = static_cast<const uint16_t*>(x);
+    if (int e = amil_bf16_forward_impl(d, xb, workspace, workspace_bytes, nullptr, A_raw, stream, false, &tl)) return e;
+    return amil_bf16_backward_impl(d, xb, workspace, workspace_bytes, nullptr, A_raw, nullptr, nullptr, grads, stream, acc);
+  }
+  const float* xf = static_cast<const float*>(x);
+  if (int e = amil_forward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, stream, false, &tl)) return e;
+  return amil_backward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, nullptr, nullptr, grads, stream, acc);
 }
 
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,

@@ -23,6 +23,11 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   uint32_t drop_key;
   const uint32_t* seed_dev;   // optional device-resident seed added to every key (graph-replay-safe dropout), or null
   int mt_count, nt_count;
+  // optional: one bit per output element, y > 0 (relu'(u) . keep), for K-dh's epilogue -- which then does not have to
+  // read h a second time.  Layout: per 32x32 block (row block rb = row / 32, column block cb = col / 32) 16 words of
+  // 64 bits, word 4 t + e = wave ballot over the row-major epilogue lanes (lane = 8 rr + c4 holds row rr + 8 t,
+  // column 4 c4 + e of the block): bits[(rb * (N / 32) + cb) * 16 + 4 t + e].  Needs N % 32 == 0.
+  unsigned long long* relu_bits;
 };
 
 struct GateFwdParams {
@@ -38,6 +43,26 @@ struct GateFwdParams {
   int mt_count, nt_count;
 };
 
+// Optional tail of K-merge, run by the LAST of its workgroups to finish (a ticket counter in the workspace): the
+// classifier + hazard head of models/model_attention_mil_path.py:58-61 and, when Y is given, nll_surv
+// (utils/loss_utils.py:22-39) with its backward down to dM -- the three single-workgroup launches
+// (surv_head_fwd, nll_surv, surv_head_bwd) that otherwise follow K-merge, each ~5 us of pure launch latency.
+struct HeadTail {
+  const float *Wk, *bk;        // [K x H], [K]; Wk == null: no tail
+  int K;
+  float *logits, *hazards, *S; // [K] each
+  int64_t* Y_hat;              // [1]
+  float* risk;                 // [1] = -sum_k S_k, or null
+  unsigned* ticket;            // workspace word, zero when K-merge starts (see PoolParams::zero_word)
+  // nll_surv + backward (Y == null: head only)
+  const int64_t* Y; const float* c;
+  float alpha, eps, loss_scale;
+  float *loss;                 // [1], unscaled
+  float *dM;                   // [H]   d(loss * loss_scale)/dM
+  float *dWk, *dbk;            // [K x H], [K]; overwritten, or added to when accumulate != 0
+  int accumulate;
+};
+
 struct PoolParams {
   const float* s_part;
   int n_parts;
@@ -50,6 +75,8 @@ struct PoolParams {
   float* M;                // [H]
   float* stats;            // {max, denom}
   int n_groups, rows_per_group;
+  HeadTail tail;
+  unsigned* zero_word;     // K-pool's block 0 clears it (the ticket of the K-merge launch that follows), or null
 };
 
 struct BwdPrepParams {     // ds_i = p_i (dM.h_i - dM.M) + gA_i
@@ -122,6 +149,7 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   const float* p;          // [N]  (read when !fused_prep)
   const float* dM;         // [H]
   const float* h;          // [N x H]
+  const unsigned long long* relu_bits;   // LinearParams::relu_bits of the forward, or null (then h is re-read in the epilogue)
   float* du;               // [N x H]
   int64_t N;
   int H;
@@ -173,7 +201,7 @@ struct NnParams {          // C[M x N] = A[M x K] . B[K x N]   (plain; radio: dh
 };
 
 struct ReduceSeg { const float* in; float* out; int len; int nsplit; size_t stride; int block_begin; int tall; };
-struct ReduceParams { ReduceSeg seg[12]; int nseg; };
+struct ReduceParams { ReduceSeg seg[12]; int nseg; int accumulate; };   // accumulate: out += sum instead of out = sum
 
 int launch_linear(LinearParams p, hipStream_t st);
 int gate_parts(int D, int gated, int64_t N);

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from ..utils.utils import initialize_weights
-from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, make_amil_stack
+from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, amil_stack_nll_step, make_amil_stack
 
 
 class MIL_Attention_fc_path(nn.Module):
@@ -38,3 +38,15 @@ class MIL_Attention_fc_surv_path(MIL_Attention_fc_path):
             return M if want_embedding else A_raw
         # (hazards, S, Y_hat, A_raw): stack + classifier + hazard head as one autograd node
         return amil_stack_head(self.attention_net_WSI, self.classifier, bag, self.training)
+
+    def nll_step(self, path_features, label, c, alpha=0.0, loss_scale=1.0, grad_out=None, accumulate=None):
+        """Extension of the reference surface (the training loop mirror uses it, utils/core_utils.py): forward +
+        NLLSurvLoss(alpha) + backward of one bag in ONE C-ABI call -- what `hazards, S, Y_hat, A_raw = model(...)`,
+        `loss = loss_fn(hazards=hazards, S=S, Y=label, c=c)`, `(loss * loss_scale).backward()` compute together
+        (models/model_attention_mil_path.py:50-72 + utils/loss_utils.py:22-39 + autograd), with the same dropout draw.
+        Gradients land in the parameters' .grad (accumulated) -- or in `grad_out`, tensors in self.parameters() order,
+        overwritten unless `accumulate`; returns (hazards, S, Y_hat, A_raw, loss, risk)."""
+        if any(not p.requires_grad for p in self.parameters()):
+            raise RuntimeError("nll_step needs every parameter of the head to require grad")
+        return amil_stack_nll_step(self.attention_net_WSI, self.classifier, path_features, self.training, label, c,
+                                   alpha, loss_scale, grad_out, accumulate)

@@ -249,6 +249,45 @@ def amil_stack(seq, x, training):
     return ops.amil_pool(x, lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
 
 
+def amil_stack_nll_step(seq, classifier, x, training, Y, c, alpha, loss_scale=1.0, grad_out=None, accumulate=None):
+    """The whole training step of one bag -- stack, classifier / hazard head, nll_surv and the backward -- as ONE C-ABI
+    call (ops.amil_nll_step), gradients of loss * loss_scale ADDED to the parameters' .grad exactly as
+    `(loss * loss_scale).backward()` would (parameters whose .grad is None get a fresh buffer, as autograd does; when
+    all of them are None the kernels write instead of accumulate and nothing is zero-filled).
+    grad_out: instead of .grad, a list of gradient tensors in the order of [*seq.parameters(), *classifier.parameters()]
+    (pipeline.BagsInFlight hands in views of a stream's gradient slot) with `accumulate` said explicitly.
+    Returns (hazards, S, Y_hat, A_raw, loss, risk), all detached."""
+    import torch
+    from .. import ops
+    lin, att = seq[0], seq[3]
+    gated = isinstance(att, Attn_Net_Gated)
+    Wa, ba, Wb, bb, Wc, bc = att.stack_params()
+    params = [lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc, classifier.weight, classifier.bias]
+    live = [p for p in params if p is not None]
+    if grad_out is not None:
+        it = iter(grad_out)
+        grads = [None if p is None else next(it) for p in params]
+        accumulate = bool(accumulate)
+    else:
+        missing = [p for p in live if p.grad is None]
+        accumulate = len(missing) < len(live)
+        if missing:
+            n = sum(p.numel() for p in missing)
+            flat = (torch.zeros if accumulate else torch.empty)(n, dtype=torch.float32, device=x.device)
+            off = 0
+            for p in missing:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        grads = [None if p is None else p.grad for p in params]
+    p_h = seq[2].p if training else 0.0
+    p_att = 0.25 if (training and att.att_dropout) else 0.0
+    seed = ops.next_dropout_seed() if training else 0
+    with torch.no_grad():
+        return ops.amil_nll_step(x, (lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc), classifier.weight, classifier.bias,
+                                 gated, Y, c, alpha, grads, loss_scale=loss_scale, accumulate=accumulate,
+                                 p_h=p_h, p_att=p_att, seed=seed)
+
+
 def amil_stack_head(seq, classifier, x, training):
     """amil_stack followed by the classifier / hazard head as one autograd node -> (hazards, S, Y_hat, A_raw)."""
     from .. import ops

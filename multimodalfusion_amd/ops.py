@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AmilDesc, AmilGrads, check, lib, ptr, stream_ptr
+from ._lib import AmilDesc, AmilGrads, NllTarget, SurvHead, check, lib, ptr, stream_ptr
 
 ACT = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}
 
@@ -96,6 +96,7 @@ class AmilPoolFn(torch.autograd.Function):
         ctx.seed_word = word
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw)
+        ctx.set_materialize_grads(False)      # an unused output (A_raw, mostly) must not cost a zero-fill launch
         return M, A_raw
 
     @staticmethod
@@ -172,24 +173,30 @@ class AmilHeadFn(torch.autograd.Function):
         word = _seed_word
         d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, word)
         l = lib()
-        ws_fn, fwd_fn = ((l.mmf_amil_bf16_workspace_bytes, l.mmf_amil_bf16_forward) if bf16
-                         else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
-        nbytes = ws_fn(N, L, H, D, d.gated)
+        nbytes = (l.mmf_amil_bf16_workspace_bytes if bf16 else l.mmf_amil_workspace_bytes)(N, L, H, D, d.gated)
         dev = x.device
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         M = torch.empty((1, H), dtype=torch.float32, device=dev)
         A_raw = torch.empty((1, N), dtype=torch.float32, device=dev)
-        st = stream_ptr()
-        check(fwd_fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), st), "mmf_amil_forward")
         out = torch.empty((3, 1, K), dtype=torch.float32, device=dev)        # logits, hazards, S
         Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
-        check(l.mmf_surv_head_forward(ptr(M), ptr(Wk), ptr(bk), 1, H, K, ptr(out[0]), ptr(out[1]), ptr(out[2]),
-                                      ptr(Y_hat), st), "mmf_surv_head_forward")
+        st = stream_ptr()
+        if K <= 32:      # the head runs as the tail of the pooling merge kernel: one launch less
+            hd = SurvHead(Wk=ptr(Wk), bk=ptr(bk), K=K, logits=ptr(out[0]), hazards=ptr(out[1]), S=ptr(out[2]),
+                          Y_hat=ptr(Y_hat), risk=None)
+            check(l.mmf_amil_head_forward(C.byref(d), ptr(x), 1 if bf16 else 0, ptr(ws), nbytes, C.byref(hd), ptr(M),
+                                          ptr(A_raw), st), "mmf_amil_head_forward")
+        else:
+            fwd_fn = l.mmf_amil_bf16_forward if bf16 else l.mmf_amil_forward
+            check(fwd_fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), st), "mmf_amil_forward")
+            check(l.mmf_surv_head_forward(ptr(M), ptr(Wk), ptr(bk), 1, H, K, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                          ptr(Y_hat), st), "mmf_surv_head_forward")
         ctx.cfg = (N, L, H, D, K, bool(gated), float(p_h), float(p_att), seed, bf16)
         ctx.seed_word = word
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, M, A_raw, out)
         ctx.mark_non_differentiable(Y_hat)
+        ctx.set_materialize_grads(False)      # no zero-fill launches for the outputs the loss does not use (A_raw, Y_hat)
         return out[1], out[2], Y_hat, A_raw
 
     @staticmethod
@@ -221,6 +228,53 @@ class AmilHeadFn(torch.autograd.Function):
         check(bwd_fn(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(M), ptr(A_raw), ptr(dM), ptr(gA), C.byref(g), st),
               "mmf_amil_backward")
         return dx, dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, dWk, dbk, None, None, None, None
+
+
+def amil_nll_step(x, stack, Wk, bk, gated, Y, c, alpha, grads, loss_scale=1.0, accumulate=False, p_h=0.0, p_att=0.0,
+                  seed=0, eps=1e-7):
+    """One bag's whole training step in ONE C-ABI call (include/mmf_amil.h: mmf_amil_nll_step): attention stack +
+    classifier / hazard head + nll_surv + backward.  No autograd graph is built.
+
+    stack = (W1, b1, Wa, ba, Wb, bb, Wc, bc); grads = the matching gradient tensors (dW1, db1, dWa, dba, dWb, dbb, dWc,
+    dbc, dWk, dbk), written with d(loss * loss_scale) -- added to when `accumulate`.  Y, c: device tensors [1].
+    Returns (hazards [1 x K], S [1 x K], Y_hat [1 x 1], A_raw [1 x N], loss (0-dim, unscaled), risk [1])."""
+    bf16 = x.dtype == torch.bfloat16
+    x = x.contiguous() if bf16 else _f32c(x)
+    W1, b1, Wa, ba, Wb, bb, Wc, bc = stack
+    W1, b1, Wa, ba, Wc, bc, Wk, bk = map(_f32c, (W1, b1, Wa, ba, Wc, bc, Wk, bk))
+    Wb, bb = _f32c(Wb), _f32c(bb)
+    if x.dim() != 2:
+        raise _lib.MmfError(f"bag must be [N x L], got {tuple(x.shape)}")
+    N, L = x.shape
+    H, D, K = W1.shape[0], Wa.shape[0], Wk.shape[0]
+    if W1.shape[1] != L or Wa.shape[1] != H or Wc.numel() != D or Wk.shape[1] != H or K > 32:
+        raise _lib.MmfError("attention stack / classifier shapes do not match the bag")
+    dW1, db1, dWa, dba, dWb, dbb, dWc, dbc, dWk, dbk = grads
+    for g_, w_ in ((dW1, W1), (db1, b1), (dWa, Wa), (dba, ba), (dWc, Wc), (dbc, bc), (dWk, Wk), (dbk, bk)) + \
+            (((dWb, Wb), (dbb, bb)) if gated else ()):
+        if g_ is None or g_.dtype != torch.float32 or g_.shape != w_.shape or not g_.is_contiguous():
+            raise _lib.MmfError("gradient buffers must be contiguous float32 tensors shaped like their parameters")
+    dev = x.device
+    if not Y.is_cuda and bool(((Y < 0) | (Y >= K)).any()):
+        raise IndexError(f"nll_surv: label out of range [0, {K})")
+    Y = Y.reshape(1).to(device=dev, dtype=torch.int64)
+    c = c.reshape(1).to(device=dev, dtype=torch.float32)
+    d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, _seed_word)
+    l = lib()
+    nbytes = (l.mmf_amil_bf16_workspace_bytes if bf16 else l.mmf_amil_workspace_bytes)(N, L, H, D, d.gated)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    A_raw = torch.empty((1, N), dtype=torch.float32, device=dev)
+    out = torch.empty((3 * K + 2,), dtype=torch.float32, device=dev)       # logits, hazards, S, loss, risk
+    Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
+    hd = SurvHead(Wk=ptr(Wk), bk=ptr(bk), K=K, logits=ptr(out[0:K]), hazards=ptr(out[K:2 * K]), S=ptr(out[2 * K:3 * K]),
+                  Y_hat=ptr(Y_hat), risk=ptr(out[3 * K + 1:]))
+    tg = NllTarget(Y=ptr(Y), c=ptr(c), alpha=float(alpha), eps=float(eps), loss_scale=float(loss_scale),
+                   loss=ptr(out[3 * K:]), dWk=ptr(dWk), dbk=ptr(dbk), accumulate=1 if accumulate else 0)
+    g = AmilGrads(dW1=ptr(dW1), db1=ptr(db1), dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb) if gated else None,
+                  dbb=ptr(dbb) if gated else None, dWc=ptr(dWc), dbc=ptr(dbc), dx=None)
+    check(l.mmf_amil_nll_step(C.byref(d), ptr(x), 1 if bf16 else 0, ptr(ws), nbytes, C.byref(hd), C.byref(tg),
+                              ptr(A_raw), C.byref(g), stream_ptr()), "mmf_amil_nll_step")
+    return (out[K:2 * K].view(1, K), out[2 * K:3 * K].view(1, K), Y_hat, A_raw, out[3 * K].view(()), out[3 * K + 1:].view(1))
 
 
 def amil_head(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h=0.0, p_att=0.0, seed=0):
@@ -298,6 +352,7 @@ class SurvHeadFn(torch.autograd.Function):
                                           ptr(S), ptr(Y_hat), stream_ptr()), "mmf_surv_head_forward")
         ctx.save_for_backward(feat, Wk, hazards)
         ctx.mark_non_differentiable(Y_hat)
+        ctx.set_materialize_grads(False)
         return hazards, S, Y_hat
 
     @staticmethod

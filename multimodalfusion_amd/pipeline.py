@@ -24,8 +24,11 @@ class BagsInFlight:
         self.n = max(1, int(n_streams))
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
         numel = sum(p.numel() for p in self.params)
-        self.slots = torch.zeros((self.n, numel), dtype=torch.float32, device=self.device)
+        # rows padded to 16 bytes: the kernels of the one-call step store float4s into the slot views
+        self._rows = torch.zeros((self.n, (numel + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+        self.slots = [self._rows[k, :numel] for k in range(self.n)]
         self._count = 0
+        self._views = None
         self._used = [False] * self.n
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
@@ -58,6 +61,31 @@ class BagsInFlight:
                 torch.cat(pieces, out=self.slots[i])          # straight into the slot: one launch
             self._used[i] = True
         return loss
+
+    def run_fused(self, model, bag, label, c, alpha, loss_scale=1.0, accumulate: bool = True, inputs=()):
+        """Issue one bag through the model's one-call step (model.nll_step: forward + nll_surv + backward in one C-ABI
+        call): the kernels write the gradients straight into the views of this stream's slot -- no autograd graph, no
+        concatenation launch.  Same stream ordering as run().  Returns nll_step's tuple (tensors on that stream)."""
+        i = self._count % self.n
+        self._count += 1
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        for t in tuple(inputs) + (bag, label, c):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(st)
+        if self._views is None:
+            self._views = []
+            for k in range(self.n):
+                off, vs = 0, []
+                for p in self.params:
+                    vs.append(self.slots[k][off:off + p.numel()].view_as(p))
+                    off += p.numel()
+                self._views.append(vs)
+        with torch.cuda.stream(st):
+            out = model.nll_step(bag, label, c, alpha=alpha, loss_scale=loss_scale, grad_out=self._views[i],
+                                 accumulate=accumulate and self._used[i])
+            self._used[i] = True
+        return out
 
     def all_reduce_slot(self, group=None):
         """Multi-GPU benchmark helper: all-reduce the slot of the bag issued last, on its stream (the collective of

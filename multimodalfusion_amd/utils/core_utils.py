@@ -65,6 +65,15 @@ def _skip(mode, radio_features, path_features, genomic_features):
     return False
 
 
+def _fused_step_ok(model, loss_fn, feats):
+    """One bag = one C-ABI call (model.nll_step): the pathology head with the stock NLLSurvLoss, a single bag tensor,
+    no autograd hooks that a graph-free step would bypass."""
+    return (type(loss_fn) is NLLSurvLoss and hasattr(model, "nll_step") and torch.is_tensor(feats.get("path_features"))
+            and feats["path_features"].dim() == 2 and feats["path_features"].is_cuda
+            and not model._forward_hooks and not model._forward_pre_hooks and not model._backward_hooks
+            and all(p.requires_grad for p in model.parameters()))
+
+
 class _Window:
     """Gradient accumulation window of `train_loop_survival`, kept on the optimizer object between calls because the
     reference's accumulated gradients survive the end of an epoch (a trailing partial window is NOT stepped and NOT
@@ -204,7 +213,11 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
                     return -torch.sum(S, dim=1), loss_fn(hazards=hazards, S=S, Y=label, c=c)
                 raise NotImplementedError(type(loss_fn))
 
-            if pipe is not None:
+            fused_step = _fused_step_ok(model, loss_fn, feats)
+            if pipe is not None and fused_step:
+                _, _, _, _, loss, risk = pipe.run_fused(model, feats["path_features"], label, c, loss_fn.alpha,
+                                                        loss_scale=1.0 / G)
+            elif pipe is not None:
                 box = {}
 
                 def bag():
@@ -213,6 +226,10 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
 
                 pipe.run(bag, inputs=list(feats.values()) + [label, c])
                 risk, loss = box["risk"], box["loss"]
+            elif fused_step:
+                # forward + nll_surv + backward of the bag in one call; the gradient of loss / G is already in .grad
+                _, _, _, _, loss, risk = model.nll_step(feats["path_features"], label, c, alpha=loss_fn.alpha,
+                                                        loss_scale=1.0 / G)
             else:
                 risk, loss = forward_loss()
             if fused_tail:
@@ -227,7 +244,10 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
             all_c.append(c.detach().reshape(-1))
             all_t.append(np.asarray(event_time).reshape(-1))
             # the reference: loss = loss / gc + loss_reg ; backward (core_utils.py:242-243)
-            if pipe is None:
+            if fused_step:
+                if not fused_tail and torch.is_tensor(loss_reg) and loss_reg.requires_grad:
+                    loss_reg.backward()          # the autograd L1 term touches parameters only
+            elif pipe is None:
                 (loss / G if fused_tail else loss / G + loss_reg).backward()
             win.kept += 1
         # window boundary: the last position of this rank's window is `last`; (last + 1) % G == 0 as the reference's

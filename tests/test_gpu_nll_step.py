@@ -1,0 +1,154 @@
+"""GPU parity of the one-call training step (include/mmf_amil.h: mmf_amil_nll_step; model.nll_step): attention stack +
+classifier / hazard head + nll_surv + backward in one C-ABI call, the head and the loss running as the tail of the
+pooling merge kernel.  Checked against the fp64 oracle with the usual bars (scores / hazards 1e-4, loss 1e-5,
+gradients 1e-5 + 1e-4 max|g|), against the autograd surface (model -> NLLSurvLoss -> backward) and for its
+accumulate / loss_scale semantics (the reference's `loss / gc` + .backward() over a window, utils/core_utils.py:242-243)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bf16_port, cases
+from test_gpu_bf16 import compare_bf16
+from test_gpu_path import DEV, _grads, _load, _t, compare, run_path_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def run_step(m, monkeypatch=None, bf16=False, loss_scale=1.0, x_np=None):
+    from multimodalfusion_amd import ops
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    sd, x, _ = cases.path_inputs(m)
+    if x_np is not None:
+        x = x_np
+    model = _load(MIL_Attention_fc_surv_path(gate_path=m["gated"], model_size_wsi=m["size"], dropout=m["dropout"],
+                                             n_classes=m["K"]), sd)
+    if m["train"]:
+        model.train()
+        monkeypatch.setattr(ops, "next_dropout_seed", lambda: m["mask_seed"])
+    else:
+        model.eval()
+    xt = _t(x).to(torch.bfloat16) if bf16 else _t(x)
+    hz, S, Yh, A_raw, loss, risk = model.nll_step(xt, torch.tensor([m["y"]]), torch.tensor([float(m["c"])]),
+                                                  alpha=m["alpha"], loss_scale=loss_scale)
+    torch.cuda.synchronize()
+    assert abs(float(risk) + float(S.sum())) < 1e-6
+    return dict(hazards=hz.cpu().numpy(), S=S.cpu().numpy(), Y_hat=Yh.cpu().numpy(), A_raw=A_raw.cpu().numpy(),
+                loss=float(loss), M=None, grads=_grads(model)), model
+
+
+def test_step_matches_oracle_on_golden_cases(golden, monkeypatch):
+    g = golden("path")
+    n = 0
+    for name, m in g.meta.items():
+        if m["N"] > 2000:
+            continue
+        res, _ = run_step(m, monkeypatch)
+        compare(res, cases.run_path(m), name + "/step")
+        assert np.array_equal(res["Y_hat"], g[name + "/f64/Y_hat"])
+        n += 1
+    assert n >= 8
+
+
+@pytest.mark.parametrize("N,gated,K", [(1, True, 4), (63, False, 4), (4097, True, 8), (20011, True, 4), (18001, False, 8)])
+def test_step_ragged_sizes_and_heads(N, gated, K, monkeypatch):
+    m = dict(N=N, gated=gated, size="small", K=K, dropout=False, y=N % K, c=N % 2, alpha=0.2, bias_std=0.05,
+             train=N > 100, seed=7000 + N, x_seed=7100 + N, mask_seed=909)
+    res, _ = run_step(m, monkeypatch)
+    from test_gpu_path import relu_kink_units
+    sd, x, _ = cases.path_inputs(m)
+    compare(res, cases.run_path(m), f"step N={N}", kink_units=relu_kink_units(sd, x) if N > 10000 else None)
+
+
+def test_step_equals_the_autograd_surface(monkeypatch):
+    """Same weights, bag and dropout seed through model -> NLLSurvLoss -> backward and through nll_step: the big kernels
+    are the same launches, only the head / loss arithmetic moved into the merge kernel's tail."""
+    m = dict(N=3001, gated=True, size="small", K=4, dropout=True, y=2, c=0, alpha=0.3, bias_std=0.05, train=True,
+             seed=31, x_seed=32, mask_seed=33)
+    a = run_path_hip(m, monkeypatch)
+    b, _ = run_step(m, monkeypatch)
+    assert abs(a["loss"] - b["loss"]) <= 1e-6
+    np.testing.assert_allclose(b["hazards"], a["hazards"], rtol=0, atol=1e-6)
+    assert np.array_equal(b["A_raw"], a["A_raw"])
+    for k, g in a["grads"].items():
+        np.testing.assert_allclose(b["grads"][k], g, rtol=1e-4, atol=1e-7 + 1e-5 * float(np.abs(g).max()), err_msg=k)
+
+
+def test_step_accumulates_like_backward_over_a_window():
+    """Two bags with loss_scale = 1/2 into the same .grad == the reference's gc = 2 window; a third call after the grads
+    were set to None starts from scratch (no stale sums)."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    m = dict(N=900, gated=True, size="small", K=4, dropout=False, y=1, c=0, alpha=0.0, bias_std=0.05, train=False,
+             seed=41, x_seed=42, mask_seed=0)
+    sd, x1, _ = cases.path_inputs(m)
+    x2 = cases.path_inputs(dict(m, x_seed=43, N=1300))[1]
+    bags = [(_t(x1), 1, 0.0), (_t(x2), 3, 1.0)]
+    ref_model = _load(MIL_Attention_fc_surv_path(gate_path=True, n_classes=4), sd).eval()
+    for xb, y, c in bags:
+        hz, S, _, _ = ref_model(path_features=xb)
+        (NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([y], device=DEV), c=torch.tensor([c], device=DEV)) / 2).backward()
+    want = _grads(ref_model)
+    model = _load(MIL_Attention_fc_surv_path(gate_path=True, n_classes=4), sd).eval()
+    for xb, y, c in bags:
+        model.nll_step(xb, torch.tensor([y]), torch.tensor([c]), alpha=0.0, loss_scale=0.5)
+    got = _grads(model)
+    for k, g in want.items():
+        np.testing.assert_allclose(got[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * float(np.abs(g).max()), err_msg=k)
+    for p in model.parameters():
+        p.grad = None
+    model.nll_step(bags[0][0], torch.tensor([1]), torch.tensor([0.0]), alpha=0.0, loss_scale=1.0)
+    one = _load(MIL_Attention_fc_surv_path(gate_path=True, n_classes=4), sd).eval()
+    hz, S, _, _ = one(path_features=bags[0][0])
+    NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([1], device=DEV), c=torch.tensor([0.0], device=DEV)).backward()
+    for k, g in _grads(one).items():
+        np.testing.assert_allclose(_grads(model)[k], g, rtol=1e-4, atol=1e-7 + 1e-5 * float(np.abs(g).max()), err_msg=k)
+
+
+def test_step_bf16_bag_vs_bf16_oracle(monkeypatch):
+    m = dict(seed=3, gated=True, size="small", K=4, dropout=True, bias_std=0.02, x_seed=77, N=4099, train=True,
+             mask_seed=4242, y=1, c=0, alpha=0.0)
+    sd, x, masks = cases.path_inputs(m)
+    xq = bf16_port.rb(bf16_port._t(x)).numpy()
+    res, _ = run_step(m, monkeypatch, bf16=True, x_np=xq)
+    ref = bf16_port.path_step_bf16(sd, xq, m["y"], m["c"], m["alpha"], gated=True, dropout=True, masks=masks)
+    compare_bf16(res, ref, "step bf16", a_tol=5e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
+
+
+def test_step_label_out_of_range_poisons_the_loss_not_the_memory():
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    torch.manual_seed(0)
+    model = MIL_Attention_fc_surv_path(gate_path=True, n_classes=4).to(DEV).eval()
+    x = torch.randn(500, 1024, device=DEV)
+    with pytest.raises(IndexError):
+        model.nll_step(x, torch.tensor([4]), torch.tensor([0.0]))            # host label: checked for free
+    out = model.nll_step(x, torch.tensor([7], device=DEV), torch.tensor([0.0], device=DEV))   # device label: kernel check
+    assert torch.isnan(out[4])
+
+
+def test_train_loop_takes_the_one_call_step(golden):
+    """utils/core_utils.train_loop_survival on the pathology head with the stock NLLSurvLoss runs the one-call step and
+    still reproduces the reference's 2-step Adam trajectory (gc = 2, l1_reg_all through autograd)."""
+    from conftest import check_summary
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils import core_utils
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    from multimodalfusion_amd.utils.utils import l1_reg_all
+    from test_gpu_train_loop import _setup
+    g, meta, sd, model, loader = _setup(golden)
+    calls = []
+    step0 = model.nll_step
+    model.nll_step = lambda *a, **k: (calls.append(1), step0(*a, **k))[1]
+    opt = torch.optim.Adam(model.parameters(), lr=meta["lr"], weight_decay=meta["reg"])
+    snaps = []
+    ostep = opt.step
+    opt.step = lambda *a, **k: (ostep(*a, **k), snaps.append({k2: v.detach().cpu().numpy().copy()
+                                                               for k2, v in model.state_dict().items()}))[0]
+    out = core_utils.train_loop_survival(0, model, loader, opt, meta["K"], "path", loss_fn=NLLSurvLoss(alpha=0.0),
+                                         reg_fn=l1_reg_all, lambda_reg=meta["lambda_reg"], gc=meta["gc"])
+    assert len(calls) == len(loader)
+    np.testing.assert_allclose(out["losses"], g["f64/losses"], atol=1e-5)
+    np.testing.assert_allclose(out["risks"], g["f64/risks"], atol=1e-4)
+    assert len(snaps) == 2
+    for si, snap in enumerate(snaps, start=1):
+        for k, v in snap.items():
+            check_summary(g, f"f64/step{si}/{k}", v, rtol=2e-5, atol=2e-6)
