@@ -161,6 +161,20 @@ int mmf_amil_bf16_infer(const mmf_amil_desc* desc, const uint16_t* x, void* work
                         float* M, float* A_raw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The attention scorer on its own: Attn_Net(L, D).forward(x) / Attn_Net_Gated(L, D).forward(x) -> (A, x)
+ *   (models/model_modules.py:84-85 and :105-110; n_classes = 1):  A[i] = (tanh(x_i Wa^T + ba) [. sigmoid(x_i Wb^T + bb)]) Wc^T + bc,
+ *   with Dropout(0.25) on the branches when desc->p_att > 0.  Same kernels as inside the stack (K-gate, K-dh, K-tn).
+ *   desc: N, H (= the scorer's input width L), D, gated, Wa..bc, p_att, seed[, seed_dev, trace]; L, W1, b1, p_h are ignored.
+ *   H % 32 == 0, D % 32 == 0.  forward keeps a, b in the workspace for the matching backward.
+ *   backward: gA [N] = dL/dA -> grads->dWa, dba, (dWb, dbb,) dWc, dbc and, when grads->dx != NULL, dx [N x H].
+ * ------------------------------------------------------------------------------------------- */
+size_t mmf_attn_net_workspace_bytes(int64_t N, int32_t H, int32_t D, int32_t gated);
+int mmf_attn_net_forward(const mmf_amil_desc* desc, const float* x, void* workspace, size_t workspace_bytes, float* A,
+                         void* stream);
+int mmf_attn_net_backward(const mmf_amil_desc* desc, const float* x, void* workspace, size_t workspace_bytes,
+                          const float* gA, const mmf_amil_grads* grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense layer on MFMA:  y = dropout(act(concat_k(x_0..x_{nseg-1}) . W^T + bias))
  *   replaces torch.cat + nn.Linear of model_attention_mil_radio.py:80-82 (reduce_dim; the modality
  *   bags are never concatenated in memory) and the instance projections generally.

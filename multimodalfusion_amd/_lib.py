@@ -84,6 +84,10 @@ SYMBOLS = {
     "mmf_amil_bf16_infer_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mmf_amil_bf16_infer": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mmf_attn_net_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "mmf_attn_net_forward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mmf_attn_net_backward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.POINTER(AmilGrads), C.c_void_p]),
     "mmf_linear_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

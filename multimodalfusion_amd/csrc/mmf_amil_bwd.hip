@@ -307,7 +307,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
 #pragma unroll
     for (int nb = 0; nb < T::NB; ++nb) {
       const int col = col0 + epilogue_col<T>(nb);
-      dm4[nb] = col < p.H ? ld4(p.dM + col) : zero4();
+      dm4[nb] = (p.dM && col < p.H) ? ld4(p.dM + col) : zero4();
     }
     if (p.relu_bits) {
       // relu'(u) . keep comes as one bit per element from the forward (LinearParams::relu_bits): 16 ballot words per
@@ -361,8 +361,10 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
       for (int t = 0; t < 4; ++t) {
         const int row = row0 + r + 8 * t;
         const int rc = row < p.N ? row : (int)p.N - 1;
-        hv[s][t] = col < p.H ? ld4(p.h + (size_t)rc * p.H + col) : zero4();
-        pv[s][t] = FUSED ? p_l[r + 8 * t] : p.p[rc];
+        // p.h == null: the standalone attention scorer (mmf_attn_net_backward) -- its input is not a ReLU output, so
+        // there is no relu' mask and no pooling term: du = dP . Wab
+        hv[s][t] = !p.h ? make_float4(1.f, 1.f, 1.f, 1.f) : (col < p.H ? ld4(p.h + (size_t)rc * p.H + col) : zero4());
+        pv[s][t] = FUSED ? p_l[r + 8 * t] : (p.p ? p.p[rc] : 0.f);
       }
     };
     fetch(0, 0);

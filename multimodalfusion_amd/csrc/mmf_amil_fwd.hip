@@ -175,15 +175,40 @@ struct LoadGateW {
 };
 
 template <class T, bool GATED>
+__device__ inline void gate_fwd_tile(const GateFwdParams& p, float* lds, int row0, int nt);
+
+template <class T, bool GATED>
 __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   extern __shared__ __align__(16) float lds[];
-  constexpr int DT = GATED ? T::BN / 2 : T::BN;   // attention dims covered by one tile
   int mt, nt;
   if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
-  const int row0 = mt * T::BM, d0 = nt * DT;
+  gate_fwd_tile<T, GATED>(p, lds, (int)p.row_begin + mt * T::BM, nt);
+}
+
+// Two tile heights in ONE launch: workgroups [0, grid_big) take TB-row tiles of rows [row_begin, row_split), the rest
+// take TS-row tiles of rows [row_split, row_end).  The short tiles are dispatched last and fill what would otherwise
+// be a sparse last round of tall tiles (see launch_gate_fwd).  TB and TS have the same thread count and column width.
+template <class TB, class TS, bool GATED>
+__global__ __launch_bounds__(TB::NT) void gate_fwd_mixed_kernel(GateFwdParams p) {
+  static_assert(TB::NT == TS::NT && TB::BN == TS::BN, "mixed tiles share the launch shape");
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if ((int)blockIdx.x < p.grid_big) {
+    if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+    gate_fwd_tile<TB, GATED>(p, lds, (int)p.row_begin + mt * TB::BM, nt);
+  } else {
+    if (!tile_of_block(blockIdx.x - p.grid_big, p.mt_count2, p.nt_count, mt, nt)) return;
+    gate_fwd_tile<TS, GATED>(p, lds, (int)p.row_split + mt * TS::BM, nt);
+  }
+}
+
+template <class T, bool GATED>
+__device__ inline void gate_fwd_tile(const GateFwdParams& p, float* lds, int row0, int nt) {
+  constexpr int DT = GATED ? T::BN / 2 : T::BN;   // attention dims covered by one tile
+  const int d0 = nt * DT;
 
   LoadK<T::BM, T::NT> la;
-  la.init(p.h, p.H, row0, (int)p.N);
+  la.init(p.h, p.H, row0, (int)p.row_end);
   LoadGateW<T::BN, T::NT, GATED, false> lb;
   lb.init(p.Wa, p.Wb, p.H, p.D, d0);
 
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
           bv[0] = fast_sigmoid(vb[q].x + bb4.x); bv[1] = fast_sigmoid(vb[q].y + bb4.y);
           bv[2] = fast_sigmoid(vb[q].z + bb4.z); bv[3] = fast_sigmoid(vb[q].w + bb4.w);
         }
-        if (row < p.N && dok) {
+        if (row < p.row_end && dok) {
           const size_t o = (size_t)row * p.D + d;
           if (p.a) {     // null in forward-only (inference) calls: nothing is saved for a backward
             st4(p.a + o, make_float4(av[0], av[1], av[2], av[3]));
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   __syncthreads();
   for (int i = tid; i < T::BM; i += T::NT) {
     int row = row0 + i;
-    if (row < p.N) {
+    if (row < p.row_end) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < T::WN; ++w) s += sred[w * T::BM + i];
@@ -545,6 +570,20 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
   }
 }
 
+// A[i] = sum_t s_part[t][i] + bc : the scores alone (standalone Attn_Net / Attn_Net_Gated forward, no pooling)
+__global__ __launch_bounds__(256) void score_sum_kernel(const float* s_part, int n_parts, const float* bc, float* A, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float s = bc ? bc[0] : 0.f;
+  for (int t = 0; t < n_parts; ++t) s += s_part[(size_t)t * N + i];
+  A[i] = s;
+}
+int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A, int64_t N, hipStream_t st) {
+  { ProfScope ps("score_sum_kernel", st);
+    hipLaunchKernelGGL(score_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, s_part, n_parts, bc, A, N); }
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 // =============================================================================================
 // host launchers
 // =============================================================================================
@@ -628,18 +667,37 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   if (p.N <= 0) return MMF_OK;
   // BN = 128 always (64 gated dims, or 128 ungated dims, per tile) so that gate_parts() is size independent
   p.nt_count = gate_parts(p.D, p.gated, p.N);
-  const bool big = (p.N / 128) * p.nt_count >= 256;
-  if (big) {
-    p.mt_count = (int)((p.N + 127) / 128);
-    int grid = grid_for_tiles(p.mt_count, p.nt_count);
-    return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, true>, p, grid, st)
-                   : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, false>, p, grid, st);
-  }
+  p.row_begin = 0; p.row_end = p.N;
   using TS = Tile<64, 128, 2, 2, true, true>;
-  p.mt_count = (int)((p.N + 63) / 64);
-  int grid = grid_for_tiles(p.mt_count, p.nt_count);
-  return p.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, p, grid, st)
-                 : launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, false>, p, grid, st);
+  auto small = [&](GateFwdParams q) {
+    q.mt_count = (int)((q.row_end - q.row_begin + 63) / 64);
+    const int grid = grid_for_tiles(q.mt_count, q.nt_count);
+    return q.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, q, grid, st)
+                   : launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, false>, q, grid, st);
+  };
+  const bool big = (p.N / 128) * p.nt_count >= 256;
+  if (!big) return small(p);
+  // 128x128 tiles run two per CU: 512 slots.  A 50k bag is 1564 tiles = 3 rounds + 28 tiles, and those 28 cost most
+  // of a 4th round (132 us against 116 us for the 1536 tiles of 49,152 rows).  The rows of such a sparse last round
+  // are cut into 64-row tiles of the same launch: twice as many CUs work on them and each finishes in half the time.
+  // (A separate second launch for them was tried first and cost the 16 us back in launch latency.)
+  static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
+  int64_t mt = (p.N + 127) / 128;
+  const int64_t slots = 512, total = mt * p.nt_count, rem = total % slots;
+  if (env_mixed && total > slots && rem > 0 && rem <= slots / 4 && slots % p.nt_count == 0) {
+    mt = (total - rem) / p.nt_count;
+    p.row_split = mt * 128;
+    p.mt_count = (int)mt;
+    p.mt_count2 = (int)((p.N - p.row_split + 63) / 64);
+    p.grid_big = grid_for_tiles(p.mt_count, p.nt_count);
+    const int grid = p.grid_big + grid_for_tiles(p.mt_count2, p.nt_count);
+    return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, true>, p, grid, st)
+                   : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, false>, p, grid, st);
+  }
+  p.mt_count = (int)mt;
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, true>, p, grid, st)
+                 : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, false>, p, grid, st);
 }
 
 int pool_groups(int64_t N) {

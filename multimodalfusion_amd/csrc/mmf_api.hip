@@ -454,6 +454,8 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     fp.key_h = drop_key(d->seed, 0); fp.key_a = drop_key(d->seed, 1); fp.key_b = drop_key(d->seed, 2);
     fp.seed_dev = seed_dev;
     if (int e = launch_fused_fwd_bf16(fp, d->gated, st)) return e;
+    // (Tried: sending the rows of a sparse last round -- 782 tiles at 100k = 3 rounds of 256 + 14 -- through the three
+    // unfused kernels instead.  The fused kernel drops 173 -> 141 us, but the three small launches cost 48 us.)
     PoolParams pm{};
     pm.N = d->N; pm.H = d->H; pm.partials = w.partials; pm.M = M; pm.stats = w.stats;
     pm.n_groups = fused_fwd_tiles(d->N);
@@ -607,6 +609,116 @@ int mmf_amil_nll_step(const mmf_amil_desc* d, const void* x, int32_t x_bf16, voi
   const float* xf = static_cast<const float*>(x);
   if (int e = amil_forward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, stream, false, &tl)) return e;
   return amil_backward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, nullptr, nullptr, grads, stream, acc);
+}
+
+// ---- standalone attention scorer: Attn_Net / Attn_Net_Gated .forward(x) -> (A, x) ------------------------------
+namespace mmf {
+struct AttnWs {
+  float *a, *b, *s_part, *slab, *cs_bab, *cs_wc;
+  int parts, mstk, splits, k_per_split, tile;
+  size_t bytes;
+};
+static AttnWs carve_attn(void* base, int64_t N, int H, int D, int gated) {
+  AttnWs w{};
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += align_up(nfloat * sizeof(float), 256);
+    return r;
+  };
+  w.parts = gate_parts(D, gated, N);
+  w.mstk = gated ? 2 * D : D;
+  w.tile = tn_tile_dim(N, D);
+  const int td = w.tile;
+  const int dt = gated ? td / 2 : td;
+  const int tiles = ((D + dt - 1) / dt) * ((H + td - 1) / td);
+  w.splits = tn_splits(N, tiles, td);
+  const int64_t kps = (N + w.splits - 1) / w.splits;
+  w.k_per_split = (int)((kps + KC - 1) / KC * KC);
+  if (w.k_per_split < KC) w.k_per_split = KC;
+  w.a = take((size_t)N * D);
+  w.b = take(gated ? (size_t)N * D : 0);
+  w.s_part = take((size_t)w.parts * N);
+  w.slab = take((size_t)w.splits * w.mstk * H);
+  w.cs_bab = take((size_t)w.splits * w.mstk);
+  w.cs_wc = take((size_t)w.splits * D);
+  w.bytes = off;
+  return w;
+}
+static int check_attn(const mmf_amil_desc* d) {
+  if (!d || !d->Wa || !d->ba || !d->Wc || !d->bc) return MMF_ERR_ARG;
+  if (d->gated && (!d->Wb || !d->bb)) return MMF_ERR_ARG;
+  if (d->N < 1 || d->H % KC != 0 || d->D % 32 != 0) return MMF_ERR_SHAPE;
+  const int64_t widest = d->H > 2 * d->D ? d->H : 2 * d->D;
+  if (d->N * widest * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
+  if (d->p_att < 0.f || d->p_att >= 1.f) return MMF_ERR_ARG;
+  return MMF_OK;
+}
+}  // namespace mmf
+
+size_t mmf_attn_net_workspace_bytes(int64_t N, int32_t H, int32_t D, int32_t gated) {
+  if (N < 1) N = 1;
+  return carve_attn(nullptr, N, H, D, gated).bytes;
+}
+
+int mmf_attn_net_forward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes, float* A,
+                         void* stream) {
+  if (int e = check_attn(d)) return e;
+  if (!x || !workspace || !A) return MMF_ERR_ARG;
+  if (!aligned16(x) || !aligned16(workspace) || !aligned16(d->Wa) || (d->gated && !aligned16(d->Wb))) return MMF_ERR_ALIGN;
+  AttnWs w = carve_attn(workspace, d->N, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  GateFwdParams gp{};
+  gp.h = x; gp.Wa = d->Wa; gp.ba = d->ba; gp.Wb = d->Wb; gp.bb = d->bb; gp.Wc = d->Wc;
+  gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
+  gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
+  gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = d->seed_dev;
+  if (int e = launch_gate_fwd(gp, st)) return e;
+  return launch_score_sum(w.s_part, w.parts, d->bc, A, d->N, st);
+}
+
+int mmf_attn_net_backward(const mmf_amil_desc* d, const float* x, void* workspace, size_t workspace_bytes,
+                          const float* gA, const mmf_amil_grads* g, void* stream) {
+  if (int e = check_attn(d)) return e;
+  if (!x || !workspace || !gA || !g) return MMF_ERR_ARG;
+  if (!g->dWa || !g->dba || !g->dWc || !g->dbc || (d->gated && (!g->dWb || !g->dbb))) return MMF_ERR_ARG;
+  if (!aligned16(g->dWa) || (d->gated && !aligned16(g->dWb)) || (g->dx && !aligned16(g->dx))) return MMF_ERR_ALIGN;
+  AttnWs w = carve_attn(workspace, d->N, d->H, d->D, d->gated);
+  if (w.bytes > workspace_bytes) return MMF_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  TraceScope ts(d->trace);
+  GateBwdCtx gc{};      // ds_i = dL/dA_i: the scorer has no softmax behind it here
+  gc.a = w.a; gc.b = w.b; gc.ds = gA; gc.Wc = d->Wc; gc.D = d->D; gc.gated = d->gated;
+  gc.drop_p = d->p_att; gc.key_a = drop_key(d->seed, 1); gc.key_b = drop_key(d->seed, 2); gc.seed_dev = d->seed_dev;
+  if (g->dx) {          // dx = dP . [Wa ; Wb]  (K-dh without relu' mask and pooling term)
+    BwdDhParams dp{};
+    dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.du = g->dx; dp.N = d->N; dp.H = d->H; dp.scale_h = 1.0f;
+    if (int e = launch_bwd_dh(dp, st)) return e;
+  }
+  TnParams tp{};
+  tp.nprob = 1; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc; tp.tile = w.tile;
+  TnProblem& q = tp.prob[0];    // d[Wa ; Wb] = dP^T . x ; (dba | dbb) = colsum(dP) ; dWc = colsum(gA . a_d . b_d)
+  q.kind = TN_A_GATE; q.A = nullptr; q.lda = 0; q.M = w.mstk;
+  q.B = x; q.ldb = d->H; q.Ncols = d->H;
+  q.out = w.slab; q.split_stride = (size_t)w.mstk * d->H; q.ldc = d->H;
+  q.colsum = w.cs_bab; q.colsum_stride = w.mstk; q.colsum2 = w.cs_wc; q.colsum2_stride = d->D;
+  if (int e = launch_tn(tp, st)) return e;
+  ReduceParams rp{};
+  int n = 0;
+  auto seg = [&](const float* in, float* out, int len, int nsplit, size_t stride) {
+    rp.seg[n].in = in; rp.seg[n].out = out; rp.seg[n].len = len; rp.seg[n].nsplit = nsplit; rp.seg[n].stride = stride; ++n;
+  };
+  seg(w.slab, g->dWa, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  if (d->gated) seg(w.slab + (size_t)d->D * d->H, g->dWb, d->D * d->H, w.splits, (size_t)w.mstk * d->H);
+  seg(w.cs_bab, g->dba, d->D, w.splits, w.mstk);
+  if (d->gated) seg(w.cs_bab + d->D, g->dbb, d->D, w.splits, w.mstk);
+  seg(w.cs_wc, g->dWc, d->D, w.splits, d->D);
+  seg(gA, g->dbc, 1, (int)d->N, 1);         // d(bc) = sum_i dL/dA_i
+  rp.nseg = n;
+  return launch_reduce(rp, st);
 }
 
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,

@@ -41,6 +41,9 @@ struct GateFwdParams {
   uint32_t key_a, key_b;
   const uint32_t* seed_dev;
   int mt_count, nt_count;
+  int64_t row_begin, row_end;   // this launch's rows of the bag (set by launch_gate_fwd)
+  int64_t row_split;            // mixed launch: tall tiles cover [row_begin, row_split), short tiles [row_split, row_end)
+  int mt_count2, grid_big;      // mixed launch: short row tiles; workgroups of the tall part
 };
 
 // Optional tail of K-merge, run by the LAST of its workgroups to finish (a ticket counter in the workspace): the
@@ -208,6 +211,7 @@ int gate_parts(int D, int gated, int64_t N);
 int launch_gate_fwd(GateFwdParams p, hipStream_t st);
 int pool_groups(int64_t N);
 int launch_pool(PoolParams p, hipStream_t st);
+int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A, int64_t N, hipStream_t st);
 int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);

@@ -29,8 +29,16 @@ class Attn_Net(nn.Module):
         return a.weight, a.bias, None, None, c.weight, c.bias
 
     def forward(self, x):
-        raise NotImplementedError(
-            "Attn_Net runs fused inside the attention-MIL heads (ops.amil_pool); call the head's forward")
+        """(A [N x n_classes], x), as the reference (models/model_modules.py:84-85).  Inside a head the scorer runs fused
+        with the projection and the pooling (ops.amil_head); called on its own it runs the same K-gate / K-dh / K-tn
+        kernels through mmf_attn_net_forward / _backward."""
+        from .. import ops
+        Wa, ba, Wb, bb, Wc, bc = self.stack_params()
+        if Wc.shape[0] != 1:
+            raise NotImplementedError("the HIP attention scorer supports n_classes = 1 (every use in the reference)")
+        p_att = 0.25 if (self.training and self.att_dropout) else 0.0
+        seed = ops.next_dropout_seed() if p_att > 0 else 0
+        return ops.attn_net(x, Wa, ba, Wb, bb, Wc, bc, False, p_att, seed), x
 
 
 class Attn_Net_Gated(nn.Module):
@@ -54,8 +62,16 @@ class Attn_Net_Gated(nn.Module):
         return a.weight, a.bias, b.weight, b.bias, c.weight, c.bias
 
     def forward(self, x):
-        raise NotImplementedError(
-            "Attn_Net_Gated runs fused inside the attention-MIL heads (ops.amil_pool); call the head's forward")
+        """(A [N x n_classes], x), as the reference (models/model_modules.py:105-110).  Inside a head the scorer runs fused
+        with the projection and the pooling (ops.amil_head); called on its own it runs the same K-gate / K-dh / K-tn
+        kernels through mmf_attn_net_forward / _backward."""
+        from .. import ops
+        Wa, ba, Wb, bb, Wc, bc = self.stack_params()
+        if Wc.shape[0] != 1:
+            raise NotImplementedError("the HIP attention scorer supports n_classes = 1 (every use in the reference)")
+        p_att = 0.25 if (self.training and self.att_dropout) else 0.0
+        seed = ops.next_dropout_seed() if p_att > 0 else 0
+        return ops.attn_net(x, Wa, ba, Wb, bb, Wc, bc, True, p_att, seed), x
 
 
 def snn_stack(fc_omic, x, training, seed=None):

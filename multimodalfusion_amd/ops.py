@@ -285,6 +285,56 @@ def amil_head(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h=0.0, p_att=0
     return AmilHeadFn.apply(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, Wk, bk, gated, p_h, p_att, seed)
 
 
+class AttnNetFn(torch.autograd.Function):
+    """The attention scorer alone: x [N x L] -> A [N x 1] (models/model_modules.py:84-85 / :105-110)."""
+
+    @staticmethod
+    def forward(ctx, x, Wa, ba, Wb, bb, Wc, bc, gated, p_att, seed):
+        x, Wa, ba, Wc, bc = map(_f32c, (x, Wa, ba, Wc, bc))
+        Wb, bb = _f32c(Wb), _f32c(bb)
+        if x.dim() != 2 or Wa.shape[1] != x.shape[1] or Wc.shape[0] != 1 or Wc.shape[1] != Wa.shape[0]:
+            raise _lib.MmfError("Attn_Net: x must be [N x L] and the scorer must have n_classes = 1")
+        N, H = x.shape
+        D = Wa.shape[0]
+        word = _seed_word
+        d = AmilDesc(N=N, L=H, H=H, D=D, gated=1 if gated else 0, W1=None, b1=None, Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None, Wc=ptr(Wc), bc=ptr(bc),
+                     p_h=0.0, p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF, seed_dev=ptr(word), trace=_trace)
+        l = lib()
+        nbytes = l.mmf_attn_net_workspace_bytes(N, H, D, d.gated)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        A = torch.empty((N, 1), dtype=torch.float32, device=x.device)
+        check(l.mmf_attn_net_forward(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(A), stream_ptr()), "mmf_attn_net_forward")
+        ctx.cfg = (N, H, D, bool(gated), float(p_att), int(seed) & 0xFFFFFFFF)
+        ctx.seed_word = word
+        ctx.ws = ws
+        ctx.save_for_backward(x, Wa, ba, Wb, bb, Wc, bc)
+        return A
+
+    @staticmethod
+    def backward(ctx, gA):
+        x, Wa, ba, Wb, bb, Wc, bc = ctx.saved_tensors
+        N, H, D, gated, p_att, seed = ctx.cfg
+        gA = _f32c(gA).reshape(N)
+        d = AmilDesc(N=N, L=H, H=H, D=D, gated=1 if gated else 0, W1=None, b1=None, Wa=ptr(Wa), ba=ptr(ba),
+                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None, Wc=ptr(Wc), bc=ptr(bc),
+                     p_h=0.0, p_att=p_att, seed=seed, seed_dev=ptr(ctx.seed_word), trace=_trace)
+        new = torch.empty_like
+        dWa, dba, dWc, dbc = new(Wa), new(ba), new(Wc), new(bc)
+        dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
+        dx = new(x) if ctx.needs_input_grad[0] else None
+        g = AmilGrads(dW1=None, db1=None, dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb), dbb=ptr(dbb), dWc=ptr(dWc),
+                      dbc=ptr(dbc), dx=ptr(dx))
+        ws = ctx.ws
+        check(lib().mmf_attn_net_backward(C.byref(d), ptr(x), ptr(ws), ws.numel(), ptr(gA), C.byref(g), stream_ptr()),
+              "mmf_attn_net_backward")
+        return dx, dWa, dba, dWb, dbb, dWc, dbc, None, None, None
+
+
+def attn_net(x, Wa, ba, Wb, bb, Wc, bc, gated, p_att=0.0, seed=0):
+    return AttnNetFn.apply(x, Wa, ba, Wb, bb, Wc, bc, gated, p_att, seed)
+
+
 class LinearCatFn(torch.autograd.Function):
     """y = cat(xs, dim=1) @ W.T + b without materialising the concatenation
     (models/model_attention_mil_radio.py:80-82)."""
