@@ -108,7 +108,7 @@ int mmf_amil_bf16_backward(const mmf_amil_desc* desc, const uint16_t* x, void* w
  *   The path head's forward is stack -> classifier -> sigmoid / cumprod / argmax (models/model_attention_mil_path.py:
  *   52-61); the training loop then applies nll_surv and calls backward (utils/core_utils.py:200-243).  After the
  *   pooling kernel these are single-workgroup launches of a few microseconds each; here they run as the tail of the
- *   pooling merge kernel (its last workgroup), so a bag costs 7 launches instead of 12 -- what matters for 1k-10k bags.
+ *   pooling merge (one single-workgroup launch behind it; for small bags the merge runs there too), so a bag costs 7-8 launches instead of 13 -- what matters for 1k-10k bags.
  *   x_bf16 != 0: x is a bf16 bag (uint16_t bits) and the bf16-storage kernels run (see above).
  *   workspace: mmf_amil_workspace_bytes / mmf_amil_bf16_workspace_bytes of the same shape.
  * mmf_amil_head_forward: stack + head; M [H], A_raw [N] and the head outputs are written; backward as usual

@@ -62,7 +62,6 @@ static int launch_tiled_b(const char* name, void (*kern)(P), const P& p, int gri
 // =============================================================================================
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0 && p.zero_word) *p.zero_word = 0u;
   int si = 0;
   for (int i = 1; i < p.nseg; ++i)
     if (b >= p.seg[i].block_begin) si = i;

@@ -317,7 +317,6 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   __shared__ float red[256];
   __shared__ __align__(16) float vred[1024];   // RG * VPR == 256 float4 slots
   const int tid = threadIdx.x, g = blockIdx.x;
-  if (g == 0 && tid == 0 && p.zero_word) *p.zero_word = 0u;
   const int64_t r0 = (int64_t)g * p.rows_per_group;
   const int64_t r1 = r0 + p.rows_per_group < p.N ? r0 + p.rows_per_group : p.N;
   const int nrows = r1 > r0 ? (int)(r1 - r0) : 0;
@@ -383,10 +382,10 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(PoolParams p) {
   }
 }
 
-// Tail of K-merge (HeadTail): 1024 threads of the last workgroup.  M is read with agent-scope atomic loads: the
-// other workgroups published their columns with a fence before taking their ticket.  Everything the tail needs that
-// does not depend on M (classifier rows / columns, bias, label, censorship) is requested by EVERY workgroup at kernel
-// entry (TailPre): the tail is a chain of dependent steps, and each global load left in it costs a memory round trip.
+// Head tail (HeadTail; head_tail_kernel below): the classifier, the hazards and -- when a label is given -- nll_surv
+// with its backward down to dM, on 1024 threads.  Everything it needs that does not depend on M (classifier rows /
+// columns, bias, label, censorship) is requested at kernel entry (TailPre): the tail is a chain of dependent steps,
+// and each global load left inside it costs a memory round trip.
 struct TailPre {
   float wk_row[16];   // wave k < K: Wk[k][lane + 64 j]        (H <= 1024)
   float wk_col[8];    // thread c < H: Wk[k][c], k < min(K, 8)
@@ -412,7 +411,8 @@ __device__ inline void head_tail(const PoolParams& p, const TailPre& r, float* s
   float* Ml = sm;                 // [H]
   float* z = sm + 1024;           // [K] logits, then dz
   float *hz = z + 32, *S = z + 64, *gH = z + 96, *gS = z + 128;   // K <= 32; in LDS: indexed arrays in registers would go to scratch
-  for (int c = tid; c < H; c += 1024) Ml[c] = __hip_atomic_load(p.M + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!p.merge_in_tail)           // M comes from the K-merge launch in front (else the caller has filled Ml)
+    for (int c = tid; c < H; c += 1024) Ml[c] = p.M[c];
   __syncthreads();
   if (wave < K) {
     float acc = 0.f;
@@ -505,8 +505,6 @@ __device__ inline void head_tail(const PoolParams& p, const TailPre& r, float* s
 // loads (the first version's serial dependent loop over groups cost 115 us).
 constexpr int MERGE_MAX_GROUPS = 4096;
 __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
-  TailPre pre;
-  if (p.tail.Wk) tail_preload(p, pre);
   __shared__ float wl[MERGE_MAX_GROUPS];
   __shared__ float red[32];
   __shared__ float colred[1024];
@@ -555,19 +553,40 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
     p.M[c] = s / l;
   }
   if (blockIdx.x == 0 && tid == 0) { p.stats[0] = m; p.stats[1] = l; }
-  if (p.tail.Wk) {
-    __shared__ unsigned last;
-    __threadfence();                       // this workgroup's columns of M are visible before its ticket is
+}
+
+// The head tail as its own single-workgroup launch behind K-merge (HeadTail).  Small bags (n_groups <= TAIL_MERGE_MAX
+// partials) are merged right here as well, one launch less: thread c sums column c over the groups.
+// (First version: tail run by the LAST workgroup of K-merge, found with a ticket counter -- the fences, the atomic and
+// the re-read of M through L2 cost 12 us, more than the 5 us of this launch.)
+constexpr int TAIL_MERGE_MAX = 64;
+__global__ __launch_bounds__(1024) void head_tail_kernel(PoolParams p) {
+  __shared__ float tail_sm[1024 + 160];
+  __shared__ float wl[TAIL_MERGE_MAX];
+  __shared__ float ml[2];
+  TailPre pre;
+  tail_preload(p, pre);
+  const int tid = threadIdx.x;
+  if (p.merge_in_tail) {
+    const int stride = 2 + p.H;
+    if (tid < 64) {                                   // one wave: group maxima, weights exp(m_g - m), denominator
+      const float mg = tid < p.n_groups ? p.partials[(size_t)tid * stride] : -INFINITY;
+      const float m = wave_max(mg);
+      const float w = mg > -INFINITY ? __expf(mg - m) : 0.f;
+      const float l = wave_sum(tid < p.n_groups ? p.partials[(size_t)tid * stride + 1] * w : 0.f);
+      wl[tid] = w;
+      if (tid == 0) { ml[0] = m; ml[1] = l; p.stats[0] = m; p.stats[1] = l; }
+    }
     __syncthreads();
-    if (tid == 0) last = atomicAdd(p.tail.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (last) {
-      __threadfence();
-      __shared__ float tail_sm[1024 + 160];
-      head_tail(p, pre, tail_sm);
-      if (tid == 0) *p.tail.ticket = 0u;
+    if (tid < p.H) {
+      float acc = 0.f;
+      for (int g = 0; g < p.n_groups; ++g) acc += p.partials[(size_t)g * stride + 2 + tid] * wl[g];
+      const float mv = acc / ml[1];
+      p.M[tid] = mv;
+      tail_sm[tid] = mv;
     }
   }
+  head_tail(p, pre, tail_sm);
 }
 
 // A[i] = sum_t s_part[t][i] + bc : the scores alone (standalone Attn_Net / Attn_Net_Gated forward, no pooling)
@@ -722,8 +741,16 @@ int launch_pool(PoolParams p, hipStream_t st) {
 
 int launch_pool_merge(PoolParams p, hipStream_t st) {
   if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || p.H % 32 != 0) return MMF_ERR_SHAPE;
-  if (p.tail.Wk && (p.tail.K < 1 || p.tail.K > 32 || !p.tail.ticket)) return MMF_ERR_SHAPE;
-  { ProfScope ps("pool_merge_kernel", st); hipLaunchKernelGGL(pool_merge_kernel, dim3(p.H / 32), dim3(1024), 0, st, p); }
+  if (p.tail.Wk && (p.tail.K < 1 || p.tail.K > 32)) return MMF_ERR_SHAPE;
+  p.merge_in_tail = p.tail.Wk && p.n_groups <= TAIL_MERGE_MAX ? 1 : 0;
+  if (!p.merge_in_tail) {
+    ProfScope ps("pool_merge_kernel", st);
+    hipLaunchKernelGGL(pool_merge_kernel, dim3(p.H / 32), dim3(1024), 0, st, p);
+  }
+  if (p.tail.Wk) {
+    ProfScope ps("head_tail_kernel", st);
+    hipLaunchKernelGGL(head_tail_kernel, dim3(1), dim3(1024), 0, st, p);
+  }
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 

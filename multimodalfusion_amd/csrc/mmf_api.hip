@@ -81,7 +81,6 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 constexpr int PREP_GROUPS = 512;
 
 struct AmilWs {
-  unsigned* ticket;                  // K-merge's "last workgroup" counter (head tail)
   float *M_step, *dM_step;           // [H] each: pooled embedding and its gradient inside mmf_amil_nll_step
   unsigned long long* relu_bits;     // [ceil(N/32)][H/32][16]: h > 0 per element (LinearParams::relu_bits)
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
@@ -132,7 +131,6 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
     if (kpg < KC) kpg = KC;
     w.splits_g = sg; w.k_per_split_g = kpg;
   }
-  w.ticket = reinterpret_cast<unsigned*>(take(4));
   w.M_step = take(H);
   w.dM_step = take(H);
   w.h = take((size_t)N * H);
@@ -176,7 +174,6 @@ static int check_desc(const mmf_amil_desc* d, int elem_bytes = 4) {
 
 // ---- bf16-storage path (mmf_bf16.h) ----------------------------------------------------------
 struct AmilWsBf {
-  unsigned* ticket;
   float *M_step, *dM_step;
   bf16_t *w1, *wab, *wabT, *h, *a, *b, *du, *dP;
   float *s_part, *partials, *stats, *p, *ds, *dbc_part, *dwc_part;
@@ -205,7 +202,6 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
   const int64_t kps = (N + w.splits - 1) / w.splits;
   w.k_per_split = (int)((kps + TNB_KCH - 1) / TNB_KCH * TNB_KCH);
   w.dbc_cap = dh_bf16_row_tiles(N);
-  w.ticket = reinterpret_cast<unsigned*>(take32(4));
   w.M_step = take32(H);
   w.dM_step = take32(H);
   w.w1 = take16((size_t)H * L);
@@ -300,7 +296,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   PoolParams pp{};
   pp.s_part = w.s_part; pp.n_parts = w.parts; pp.bc = d->bc; pp.h = w.h; pp.N = d->N; pp.H = d->H;
   pp.A_raw = A_raw; pp.partials = w.partials; pp.M = M; pp.stats = w.stats;
-  if (tail) { pp.tail = *tail; pp.tail.ticket = w.ticket; pp.tail.dM = w.dM_step; pp.zero_word = w.ticket; }
+  if (tail) { pp.tail = *tail; pp.tail.dM = w.dM_step; }
   return launch_pool(pp, st);
 }
 
@@ -425,11 +421,10 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   TraceScope ts(d->trace);
   const uint32_t* const seed_dev = d->seed_dev;
   HeadTail tl{};
-  if (tail) { tl = *tail; tl.ticket = w.ticket; tl.dM = w.dM_step; }
+  if (tail) { tl = *tail; tl.dM = w.dM_step; }
 
   CvtParams cp{};
   cp.nseg = 0;
-  cp.zero_word = tail ? w.ticket : nullptr;
   auto cvt = [&](const float* src, bf16_t* dst, int rows, int cols, int dst_ld, int c0, int transpose) {
     cp.seg[cp.nseg++] = CvtSeg{src, dst, rows, cols, dst_ld, c0, transpose, 0};
   };

@@ -41,7 +41,7 @@ struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  t
   const float* src; bf16_t* dst;
   int rows, cols, dst_ld, c0, transpose, block_begin;
 };
-struct CvtParams { CvtSeg seg[6]; int nseg; unsigned* zero_word; };   // zero_word: cleared by block 0 (K-merge's ticket), or null
+struct CvtParams { CvtSeg seg[6]; int nseg; };
 
 struct LinearBfParams {    // y[M x N] = bf16(drop(relu(x[M x K] . W[N x K]^T + bias)))
   const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;

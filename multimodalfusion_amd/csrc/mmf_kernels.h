@@ -46,17 +46,16 @@ struct GateFwdParams {
   int mt_count2, grid_big;      // mixed launch: short row tiles; workgroups of the tall part
 };
 
-// Optional tail of K-merge, run by the LAST of its workgroups to finish (a ticket counter in the workspace): the
-// classifier + hazard head of models/model_attention_mil_path.py:58-61 and, when Y is given, nll_surv
-// (utils/loss_utils.py:22-39) with its backward down to dM -- the three single-workgroup launches
-// (surv_head_fwd, nll_surv, surv_head_bwd) that otherwise follow K-merge, each ~5 us of pure launch latency.
+// Optional tail behind K-merge, ONE single-workgroup launch (head_tail_kernel; for small bags it does the merge too):
+// the classifier + hazard head of models/model_attention_mil_path.py:58-61 and, when Y is given, nll_surv
+// (utils/loss_utils.py:22-39) with its backward down to dM -- instead of the three launches surv_head_fwd, nll_surv,
+// surv_head_bwd, each ~5 us of pure launch latency.
 struct HeadTail {
   const float *Wk, *bk;        // [K x H], [K]; Wk == null: no tail
   int K;
   float *logits, *hazards, *S; // [K] each
   int64_t* Y_hat;              // [1]
   float* risk;                 // [1] = -sum_k S_k, or null
-  unsigned* ticket;            // workspace word, zero when K-merge starts (see PoolParams::zero_word)
   // nll_surv + backward (Y == null: head only)
   const int64_t* Y; const float* c;
   float alpha, eps, loss_scale;
@@ -79,7 +78,7 @@ struct PoolParams {
   float* stats;            // {max, denom}
   int n_groups, rows_per_group;
   HeadTail tail;
-  unsigned* zero_word;     // K-pool's block 0 clears it (the ticket of the K-merge launch that follows), or null
+  int merge_in_tail;       // set by launch_pool_merge: the tail launch merges the (few) partials itself
 };
 
 struct BwdPrepParams {     // ds_i = p_i (dM.h_i - dM.M) + gA_i
