@@ -109,9 +109,12 @@ struct LoadP_K {   // A[i][k] = dP, k-contiguous image
   // dims (LoadWab_M walks [Wa ; Wb] in the same order; a sum does not care).  Both halves are built from the same
   // a, b, Wc values, so the odd chunk issues no loads and reuses the even chunk's registers: a and b cross HBM once
   // per tile instead of twice (PMC, 50k bag: 369 MB per launch with the [all of Wa | all of Wb] order).
-  __device__ inline void load(int kt) {
+  __device__ inline void load_meta(int kt) {
     part = g.gated ? (kt & 1) : 0;
     d0 = (g.gated ? (kt >> 1) : kt) * KC;
+  }
+  __device__ inline void load(int kt) {
+    load_meta(kt);
     if (part) return;
     const unsigned soff = (unsigned)d0 * 4u;
     wc4 = bld4(rwc, 16u * (tid & 7), soff);
@@ -195,6 +198,57 @@ struct LoadWab_M {
       if (Map::valid(tid, i)) st4(lds + Map::lds(tid, i), r[i]);
   }
 };
+
+// Deep-prefetch main loop of K-dh for short grids (see gemm_mainloop_deep): gated stacks only.  The A loader works in
+// PAIRS of chunks (chunk 2j loads a, b; chunk 2j + 1 reuses the registers), so it gets two copies, each holding one pair,
+// reloaded as soon as the pair's second chunk has been written to LDS; the B loader gets four plain copies.
+// nk % 4 == 0; branch-free for the same reason as gemm_mainloop_deep.
+template <class T, class LA, class LB>
+__device__ inline void dh_mainloop_deep(const LA& la0, const LB& lb0, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  LA la[2] = {la0, la0};
+  LB lb[4] = {lb0, lb0, lb0, lb0};
+  la[0].load(0); la[1].load(2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lb[j].load(j);
+  la[0].store(lds);
+  lb[0].store(lds + T::A_FLOATS);
+  __syncthreads();
+  constexpr int NS = chunk_steps<T>();
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kt = kt0 + j;
+      float* cur = lds + (j & 1) * T::STAGE_FLOATS;
+      float* nxt = lds + ((j + 1) & 1) * T::STAGE_FLOATS;
+      compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
+        if (s % (NS / 4) != 0) return;
+        const int q = s / (NS / 4);
+        if (q == 0) {
+          // copy c's pair is fully written once its odd chunk has been stored, i.e. after step 2c of this round
+          if (j == 1) la[0].load(kt0 + 4);
+          else if (j == 3) la[1].load(kt0 + 6);
+        } else if (q == 1) {
+          lb[j].load(kt + 4);
+        } else if (q == 2) {
+          LA& l = la[((j + 1) & 3) >> 1];
+          l.load_meta(kt + 1);                               // part / d0 of the chunk being written (no memory access)
+          l.store(nxt);
+        } else {
+          lb[(j + 1) & 3].store(nxt + T::A_FLOATS);
+        }
+      });
+      __syncthreads();
+    }
+  }
+}
 
 template <class T, bool FUSED, int MODE = -1>
 __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
@@ -292,7 +346,12 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   f32x16 acc[T::MB][T::NB];
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
   MMF_KSTAMP(k1);
-  gemm_mainloop<T, decltype(la), decltype(lb), FUSED && MODE >= 0>(la, lb, nk, lds, acc);
+  if constexpr (T::NT == 256 && T::BM <= 64) {
+    if (p.deep && p.g.gated) dh_mainloop_deep<T>(la, lb, nk, lds, acc);       // short grid: see dh_mainloop_deep
+    else gemm_mainloop<T, decltype(la), decltype(lb), false>(la, lb, nk, lds, acc);
+  } else {
+    gemm_mainloop<T, decltype(la), decltype(lb), FUSED && MODE >= 0>(la, lb, nk, lds, acc);
+  }
   MMF_KSTAMP(k2);
   // ---- epilogue: du = (acc + p dM) relu'(h) scale_h, row-major.  The h values (and p) of block b+1 are requested
   // before block b is transposed and stored: with the reload inside the block (first version) every one of the
@@ -835,9 +894,15 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 }
 
 // > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
+static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
+  return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
+}
 int bwd_dh_fused_groups(int64_t N, int H) {
   static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
-  if (!env || !use_wide_tiles(N, H)) return 0;
+  if (!env) return 0;
+  // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
+  if (dh_short_grid(N, H)) return (int)((N + 63) / 64);
+  if (!use_wide_tiles(N, H)) return 0;
   const int mb = pick_wide_mb(N, H / 256);
   return (int)((N + 32 * mb - 1) / (32 * mb));
 }
@@ -853,7 +918,7 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
       default: return launch_bwd_dh_wide<7>(p, st);
     }
   }
-  if (p.fused_prep) return MMF_ERR_ARG;
+  if (p.fused_prep && !dh_short_grid(p.N, p.H)) return MMF_ERR_ARG;
   const int ntn = (p.H + 127) / 128;
   if ((p.N / 128) * ntn >= 256) {
     using T = Tile<128, 128, 2, 2, true, false>;
@@ -862,6 +927,12 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   }
   using T = Tile<64, 64, 2, 2, true, false>;
   p.mt_count = (int)((p.N + 63) / 64); p.nt_count = (p.H + 63) / 64;
+  static const int env_deep = getenv("MMF_DEEP") ? atoi(getenv("MMF_DEEP")) : 1;     // A/B switch
+  static const int deep_cap = getenv("MMF_DEEP_MAX") ? atoi(getenv("MMF_DEEP_MAX")) : 1024;   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
+  p.deep = env_deep && (int64_t)p.mt_count * p.nt_count <= deep_cap && p.g.gated && (2 * p.g.D / KC) % 4 == 0 ? 1 : 0;
+  if (p.fused_prep)
+    return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid_for_tiles(p.mt_count, p.nt_count),
+                                 (3 * T::BM + 16) * 4, st);
   return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
@@ -884,7 +955,7 @@ int launch_nn(NnParams p, hipStream_t st) {
 // splits (slab traffic) for the same number of workgroups, so it is used only for long K.
 int tn_tile_dim(int64_t K, int D_gate) {
   static const int env = getenv("MMF_TN_WIDE") ? atoi(getenv("MMF_TN_WIDE")) : 1;
-  if (!env || K < 8192) return 128;
+  if (!env || K < 12288) return 128;      // measured crossover: 10k bags 236 vs 243 us per step, 14k 294 vs 289
   (void)D_gate;
   return 256;
 }

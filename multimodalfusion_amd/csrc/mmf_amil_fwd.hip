@@ -105,7 +105,12 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 
   f32x16 acc[T::MB][T::NB];
   MMF_KSTAMP(k0);
-  gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+  if constexpr (T::NT == 256 && T::BM <= 64) {
+    if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, p.K / KC, lds, acc);      // short grid: see gemm_mainloop_deep
+    else gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+  } else {
+    gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+  }
   MMF_KSTAMP(k1);
 #ifdef MMF_STAMPS
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], k0 - kernel_t0);     // entry -> loaders initialised
@@ -213,7 +218,12 @@ __device__ inline void gate_fwd_tile(const GateFwdParams& p, float* lds, int row
   lb.init(p.Wa, p.Wb, p.H, p.D, d0);
 
   f32x16 acc[T::MB][T::NB];
-  gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
+  if constexpr (T::BM <= 64) {
+    if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, p.H / KC, lds, acc);      // short grid: see gemm_mainloop_deep
+    else gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
+  } else {
+    gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
+  }
 
 #ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
   {
@@ -614,6 +624,13 @@ static int launch_tiled(const char* name, void (*kern)(P), const P& p, int grid,
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+// a grid this short leaves every workgroup alone on its CU: nothing hides a memory round trip but deeper prefetch
+static inline bool short_grid(int64_t workgroups) {
+  static const int env = getenv("MMF_DEEP") ? atoi(getenv("MMF_DEEP")) : 1;     // A/B switch
+  static const int cap = getenv("MMF_DEEP_MAX") ? atoi(getenv("MMF_DEEP_MAX")) : 1024;   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
+  return env && workgroups <= cap;
+}
+
 using TileNT128 = Tile<128, 128, 2, 2, true, true>;
 using TileNT64 = Tile<64, 64, 2, 2, true, true>;
 
@@ -672,6 +689,7 @@ int launch_linear(LinearParams p, hipStream_t st) {
     return launch_tiled<TileNT128>("linear_nt_kernel", linear_nt_kernel<TileNT128>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
   p.mt_count = (int)((p.M + 63) / 64); p.nt_count = (p.N + 63) / 64;
+  p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && p.nseg == 1 ? 1 : 0;
   return launch_tiled<TileNT64>("linear_nt_kernel", linear_nt_kernel<TileNT64>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
@@ -690,6 +708,7 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   using TS = Tile<64, 128, 2, 2, true, true>;
   auto small = [&](GateFwdParams q) {
     q.mt_count = (int)((q.row_end - q.row_begin + 63) / 64);
+    q.deep = short_grid(q.mt_count * q.nt_count) && (q.H / KC) % 4 == 0 ? 1 : 0;
     const int grid = grid_for_tiles(q.mt_count, q.nt_count);
     return q.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, q, grid, st)
                    : launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, false>, q, grid, st);

@@ -485,6 +485,59 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #endif
 }
 
+// Deep register prefetch for SHORT grids (small bags: a few dozen workgroups, one per CU, nothing else on the CU to
+// hide a memory round trip).  The plain loop above requests chunk kt+1 while chunk kt computes; a 64x64 tile computes
+// a chunk in ~1000 cycles, a load takes 2-4 thousand, so every chunk waited for its operands (N = 1k: 32 chunks x 0.9 us
+// for 0.4 us of MFMA each).  Here D copies of the loaders hold D chunks in flight: chunk kt+D is requested while chunk
+// kt computes and written to LDS D-1 chunks later.  LDS stays double-buffered.  The kt loop is unrolled by D so that
+// the loader copies are addressed at compile time (they live in registers).  Loaders must be plain copies (their
+// load(kt) / store(lds) pair may be split across copies): LoadK, LoadM, LoadGateW.  nk % D == 0 (checked by the
+// launchers), and the body is branch-free on purpose: the last D chunks request operands past the end (a buffer load
+// beyond the range returns zeros, within it stale columns) that nobody consumes, and the last store fills a stage
+// nobody reads.  With a branch around a load or a store hipcc can no longer count the loads in flight and falls back
+// to s_waitcnt vmcnt(0) in front of every LDS write -- which drains exactly the prefetch this loop exists for.
+template <class T, int D, class LA, class LB>
+__device__ inline void gemm_mainloop_deep(const LA& la0, const LB& lb0, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  if (nk <= 0) return;
+  LA la[D];
+  LB lb[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    la[j] = la0; lb[j] = lb0;
+    la[j].load(j); lb[j].load(j);
+  }
+  la[0].store(lds);
+  lb[0].store(lds + T::A_FLOATS);
+  __syncthreads();
+  constexpr int NS = chunk_steps<T>();
+  static_assert((D & 1) == 0, "an even D keeps the LDS stage of copy j fixed");
+  for (int kt0 = 0; kt0 < nk; kt0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int kt = kt0 + j;
+      float* cur = lds + (j & 1) * T::STAGE_FLOATS;
+      float* nxt = lds + ((j + 1) & 1) * T::STAGE_FLOATS;
+      compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
+        if (s % (NS / 4) != 0) return;
+        const int q = s / (NS / 4);
+        if (q == 0) la[j].load(kt + D);                       // copy j has been written out: reuse it
+        else if (q == 1) lb[j].load(kt + D);
+        else if (q == 2) la[(j + 1) % D].store(nxt);
+        else lb[(j + 1) % D].store(nxt + T::A_FLOATS);
+      });
+      __syncthreads();
+    }
+  }
+}
+
 // visit every accumulator element this lane owns: f(row_in_tile, col_in_tile, value)
 template <class T, class F>
 __device__ inline void for_each_c(f32x16 (&acc)[T::MB][T::NB], F&& f) {

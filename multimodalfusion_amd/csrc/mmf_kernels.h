@@ -28,6 +28,7 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   // 64 bits, word 4 t + e = wave ballot over the row-major epilogue lanes (lane = 8 rr + c4 holds row rr + 8 t,
   // column 4 c4 + e of the block): bits[(rb * (N / 32) + cb) * 16 + 4 t + e].  Needs N % 32 == 0.
   unsigned long long* relu_bits;
+  int deep;                // set by launch_linear: short grid, use the deep-prefetch main loop
 };
 
 struct GateFwdParams {
@@ -44,6 +45,7 @@ struct GateFwdParams {
   int64_t row_begin, row_end;   // this launch's rows of the bag (set by launch_gate_fwd)
   int64_t row_split;            // mixed launch: tall tiles cover [row_begin, row_split), short tiles [row_split, row_end)
   int mt_count2, grid_big;      // mixed launch: short row tiles; workgroups of the tall part
+  int deep;                     // set by launch_gate_fwd: short grid, use the deep-prefetch main loop
 };
 
 // Optional tail behind K-merge, ONE single-workgroup launch (head_tail_kernel; for small bags it does the merge too):
@@ -157,6 +159,7 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   int H;
   float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
   int mt_count, nt_count;
+  int deep;                // set by launch_bwd_dh: short grid, deep-prefetch main loop (dh_mainloop_deep)
   // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
   // in LDS for its loader / epilogue and publishes them for the TN kernel
   int fused_prep;
