@@ -589,8 +589,15 @@ __global__ __launch_bounds__(1024) void head_tail_kernel(PoolParams p) {
     }
     __syncthreads();
     if (tid < p.H) {
+      // the same order of additions as pool_merge_kernel (32 interleaved group slices, then the slices in order): the
+      // forward-only path merges there, and the two must agree to the bit (tests/test_gpu_infer.py)
+      const float* q = p.partials + 2 + tid;
       float acc = 0.f;
-      for (int g = 0; g < p.n_groups; ++g) acc += p.partials[(size_t)g * stride + 2 + tid] * wl[g];
+      for (int sl = 0; sl < 32; ++sl) {
+        float a = 0.f;
+        for (int g = sl; g < p.n_groups; g += 32) a += q[(size_t)g * stride] * wl[g];
+        acc += a;
+      }
       const float mv = acc / ml[1];
       p.M[tid] = mv;
       tail_sm[tid] = mv;
