@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 

@@ -344,13 +344,14 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   LoadWab_M<T::BN, T::NT> lb;
   lb.init(p.Wa, p.Wb, p.H, p.g.D, col0, p.g.gated != 0);
   f32x16 acc[T::MB][T::NB];
+  f32x4acc acch[T::NB][2];                   // the half block's accumulators (Tile::HALF; unused otherwise)
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
   MMF_KSTAMP(k1);
   if constexpr (T::NT == 256 && T::BM <= 64) {
     if (p.deep && p.g.gated) dh_mainloop_deep<T>(la, lb, nk, lds, acc);       // short grid: see dh_mainloop_deep
     else gemm_mainloop<T, decltype(la), decltype(lb), false>(la, lb, nk, lds, acc);
   } else {
-    gemm_mainloop<T, decltype(la), decltype(lb), FUSED && MODE >= 0>(la, lb, nk, lds, acc);
+    gemm_mainloop<T, decltype(la), decltype(lb), FUSED && MODE >= 0>(la, lb, nk, lds, acc, acch);
   }
   MMF_KSTAMP(k2);
   // ---- epilogue: du = (acc + p dM) relu'(h) scale_h, row-major.  The h values (and p) of block b+1 are requested
@@ -376,12 +377,13 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
       const int cbn = p.H >> 5;
       typedef unsigned long long u64;
       u64 mv[2];
+      // bit blocks are 16 rows x 32 columns, 8 words each (LinearParams::relu_bits): a 32-row block is two of them
       auto fetch_bits = [&](int b, int s) {
-        const int mb = b / T::NB, nb = b % T::NB;
-        const int64_t rb = ((int64_t)row0 >> 5) + wm * T::MB + mb;
+        const int mb = b / T::NB, nb = b % T::NB;       // mb == T::MB: the half block (lanes 0..7 only)
+        const int64_t rb16 = (((int64_t)row0 + wm * (T::BM / T::WM) + mb * 32) >> 4) + (lane >> 3);
         const int cb = (col0 >> 5) + wn * T::NB + nb;
-        const bool ok = rb * 32 < p.N && cb < cbn && lane < 16;
-        mv[s] = ok ? p.relu_bits[((size_t)rb * cbn + cb) * 16 + lane] : 0ull;
+        const bool ok = rb16 * 16 < p.N && cb < cbn && lane < (mb == T::MB ? 8 : 16);
+        mv[s] = ok ? p.relu_bits[((size_t)rb16 * cbn + cb) * 8 + (lane & 7)] : 0ull;
       };
       fetch_bits(0, 0);
 #pragma unroll
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
         if (b + 1 < NBLK) fetch_bits(b + 1, s ^ 1);
         float4 v[4];
         transpose_block(acc[mb][nb], blk, lane, v);
-        const int r = (wm * T::MB + mb) * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
+        const int r = wm * (T::BM / T::WM) + mb * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
         if (col >= p.H) continue;
         const float4 dm = dm4[nb];
 #pragma unroll
@@ -408,6 +410,33 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
             asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o[e]) : "v"(raw[e]), "s"(m));
           }
           if (row < p.N) st4(p.du + (size_t)row * p.H + col, make_float4(o[0], o[1], o[2], o[3]));
+        }
+      }
+      if constexpr (T::HALF) {                  // the 16-row half block of every column block
+#pragma unroll
+        for (int nb = 0; nb < T::NB; ++nb) {
+          fetch_bits(T::MB * T::NB + nb, 0);
+          float4 v[2];
+          transpose_half(acch[nb][0], acch[nb][1], blk, lane, v);
+          const int r = wm * (T::BM / T::WM) + T::MB * 32 + rr, col = col0 + (wn * T::NB + nb) * 32 + 4 * c4;
+          if (col >= p.H) continue;
+          const float4 dm = dm4[nb];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row = row0 + r + 8 * t;
+            const float pi = FUSED ? p_l[r + 8 * t] : p.p[row < p.N ? row : (int)p.N - 1];
+            const float raw[4] = {(v[t].x + pi * dm.x) * p.scale_h, (v[t].y + pi * dm.y) * p.scale_h,
+                                  (v[t].z + pi * dm.z) * p.scale_h, (v[t].w + pi * dm.w) * p.scale_h};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned lo = __builtin_amdgcn_readlane((unsigned)mv[0], 4 * t + e);
+              const unsigned hi = __builtin_amdgcn_readlane((unsigned)(mv[0] >> 32), 4 * t + e);
+              const u64 m = ((u64)hi << 32) | lo;
+              asm volatile("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o[e]) : "v"(raw[e]), "s"(m));
+            }
+            if (row < p.N) st4(p.du + (size_t)row * p.H + col, make_float4(o[0], o[1], o[2], o[3]));
+          }
         }
       }
     } else {
@@ -874,9 +903,9 @@ static int launch_tiled_extra(const char* name, void (*kern)(P), const P& p, int
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
-template <int MB>
+template <int ROWS>
 static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
-  using T = Tile<32 * MB, 256, 1, 8, true, false>;
+  using T = Tile<ROWS, 256, 1, 8, true, false>;
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
   const int grid = grid_for_tiles(p.mt_count, p.nt_count);
   if (p.fused_prep) {
@@ -897,25 +926,27 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
   return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
 }
-int bwd_dh_fused_groups(int64_t N, int H) {
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half) {
   static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
   if (dh_short_grid(N, H)) return (int)((N + 63) / 64);
   if (!use_wide_tiles(N, H)) return 0;
-  const int mb = pick_wide_mb(N, H / 256);
-  return (int)((N + 32 * mb - 1) / (32 * mb));
+  const int rows = pick_wide_rows(N, H / 256, allow_half != 0);   // the fused launch always has the forward's relu bits
+  return (int)((N + rows - 1) / rows);
 }
 
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
   if (use_wide_tiles(p.N, p.H)) {
-    switch (pick_wide_mb(p.N, p.H / 256)) {
-      case 2: return launch_bwd_dh_wide<2>(p, st);
-      case 4: return launch_bwd_dh_wide<4>(p, st);
-      case 6: return launch_bwd_dh_wide<6>(p, st);
-      default: return launch_bwd_dh_wide<7>(p, st);
+    // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
+    switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
+      case 64: return launch_bwd_dh_wide<64>(p, st);
+      case 128: return launch_bwd_dh_wide<128>(p, st);
+      case 192: return launch_bwd_dh_wide<192>(p, st);
+      case 208: return launch_bwd_dh_wide<208>(p, st);
+      default: return launch_bwd_dh_wide<224>(p, st);
     }
   }
   if (p.fused_prep && !dh_short_grid(p.N, p.H)) return MMF_ERR_ARG;

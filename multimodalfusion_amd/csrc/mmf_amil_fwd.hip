@@ -35,7 +35,8 @@ __device__ inline float apply_act(float v, int act) {
 // branches (every taken branch refills the instruction buffer); the kernel dispatches ONCE per workgroup instead.
 // ACT = -1: any activation, decided per element (the rarely used tanh / sigmoid / SELU projections).
 template <class T, int ACT, bool DROP>
-__device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], float* lds, int row0, int col0) {
+__device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], f32x4acc (*acch)[2], float* lds,
+                                       int row0, int col0) {
 #ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
   {
     float t = 0.f;
@@ -54,13 +55,16 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
     bias4[nb] = (p.bias && col < p.N) ? ld4(p.bias + col) : zero4();
   }
   const int lane = threadIdx.x & 63;
-  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+  // one transposed block: NT row groups (rows r + 8 t) of 4 consecutive columns per lane; NT = 4 for a 32-row block,
+  // 2 for the 16-row half block
+  auto rows_op = [&](auto nt_c, int nb, int r, int c, const float4* v) {
+    constexpr int NTR = decltype(nt_c)::value;
     const int col = col0 + c;
     const bool col_ok = col < p.N;           // N % 4 == 0: a float4 never straddles the edge
     const float4 b4 = bias4[nb];
     unsigned long long mine = 0ull;          // lane 4 t + e keeps ballot (t, e) of this block (LinearParams::relu_bits)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTR; ++t) {
       const int row = row0 + r + 8 * t;
       const bool ok = col_ok && row < p.M;
       float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
@@ -83,11 +87,26 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
 #endif
       if (ok) st4(p.y + (size_t)row * p.N + col, make_float4(y[0], y[1], y[2], y[3]));
     }
-    if (p.relu_bits && lane < 16) {
-      const size_t rb = (size_t)(row0 + r - (lane >> 3)) >> 5, cb = (size_t)(col0 + c - 4 * (lane & 7)) >> 5;
-      if ((int64_t)rb * 32 < p.M && (int)(cb * 32) < p.N) p.relu_bits[(rb * (size_t)(p.N >> 5) + cb) * 16 + lane] = mine;
+    if (p.relu_bits && lane < 4 * NTR) {
+      // 16-row granularity: rows r0 + rr + 8 t with t = 0, 1 are bit block r0 / 16, t = 2, 3 bit block r0 / 16 + 1
+      const size_t rb16 = ((size_t)(row0 + r - (lane >> 3)) >> 4) + (lane >> 3), cb = (size_t)(col0 + c - 4 * (lane & 7)) >> 5;
+      if ((int64_t)rb16 * 16 < p.M && (int)(cb * 32) < p.N) p.relu_bits[(rb16 * (size_t)(p.N >> 5) + cb) * 8 + (lane & 7)] = mine;
     }
+  };
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+    rows_op(std::integral_constant<int, 4>{}, nb, r, c, v);
   });
+  if constexpr (T::HALF) {
+    const int wave = threadIdx.x >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    float* blk = lds + wave * (32 * EPI_STRIDE);
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) {
+      float4 v[2];
+      transpose_half(acch[nb][0], acch[nb][1], blk, lane, v);
+      rows_op(std::integral_constant<int, 2>{}, nb, wm * (T::BM / T::WM) + T::MB * 32 + (lane >> 3),
+              (wn * T::NB + nb) * 32 + 4 * (lane & 7), v);
+    }
+  }
 }
 
 template <class T>
@@ -104,12 +123,13 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   lb.init(p.w, p.K, col0, p.N);
 
   f32x16 acc[T::MB][T::NB];
+  f32x4acc acch[T::NB][2];                   // the half block's accumulators (Tile::HALF; unused otherwise)
   MMF_KSTAMP(k0);
   if constexpr (T::NT == 256 && T::BM <= 64) {
     if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, p.K / KC, lds, acc);      // short grid: see gemm_mainloop_deep
     else gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
   } else {
-    gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+    gemm_mainloop<T>(la, lb, p.K / KC, lds, acc, acch);
   }
   MMF_KSTAMP(k1);
 #ifdef MMF_STAMPS
@@ -117,14 +137,14 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 #endif
   const bool drop = p.drop_p > 0.f;
   if (p.act == ACT_RELU) {
-    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, lds, row0, col0);
-    else linear_epilogue<T, ACT_RELU, false>(p, acc, lds, row0, col0);
+    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, acch, lds, row0, col0);
+    else linear_epilogue<T, ACT_RELU, false>(p, acc, acch, lds, row0, col0);
   } else if (p.act == ACT_NONE && !drop) {
-    linear_epilogue<T, ACT_NONE, false>(p, acc, lds, row0, col0);
+    linear_epilogue<T, ACT_NONE, false>(p, acc, acch, lds, row0, col0);
   } else if (drop) {
-    linear_epilogue<T, -1, true>(p, acc, lds, row0, col0);
+    linear_epilogue<T, -1, true>(p, acc, acch, lds, row0, col0);
   } else {
-    linear_epilogue<T, -1, false>(p, acc, lds, row0, col0);
+    linear_epilogue<T, -1, false>(p, acc, acch, lds, row0, col0);
   }
 #ifdef MMF_STAMPS
   MMF_KSTAMP(k2);
@@ -648,21 +668,23 @@ static inline bool use_big_tiles(int64_t M, int N) { return (M / 128) * ((N + 12
 // Measured (profiles/r01/load_rate.txt): a CU pulls ~11.5 B/clk of streamed and ~29 B/clk of L2-hot operand
 // into LDS; two 128x128 workgroups per CU need 64 KB per 8192 MFMA cycles and stall on it.  A 224x256 tile
 // needs 60 KB per 14336 MFMA cycles (60 FLOP/B instead of 32) and, at N = 50k, gives exactly 224 tiles.
-template <int MB>
-using TileW = Tile<32 * MB, 256, 1, 8, true, true>;
+template <int ROWS>
+using TileW = Tile<ROWS, 256, 1, 8, true, true>;
 
-// row-block count that minimises rounds x MB over the 256 CUs (0.35: per-tile prologue/epilogue, in MB units)
-int pick_wide_mb(int64_t M, int ntn) {
-  static const int env = getenv("MMF_WIDE_MB") ? atoi(getenv("MMF_WIDE_MB")) : 0;   // tuning override
-  if (env > 0) return env;
-  int best = 7;
+// tile height that minimises rounds x blocks over the 256 CUs (0.35: per-tile prologue / epilogue, in 32-row blocks);
+// 208 = six blocks + a 16-row half block (Tile::HALF): a 50k bag becomes 241 tiles on 241 CUs instead of 224
+int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
+  static const int env = getenv("MMF_WIDE_ROWS") ? atoi(getenv("MMF_WIDE_ROWS")) : 0;   // tuning override
+  if (env > 0 && (env != 208 || allow_half)) return env;
+  int best = 224;
   double bestc = 1e30;
-  const int cand[4] = {7, 6, 4, 2};   // MB = 8 needs > 256 VGPRs with double-buffered fragments (spills)
-  for (int mb : cand) {
-    int64_t tiles = ((M + 32 * mb - 1) / (32 * mb)) * ntn;
+  const int cand[5] = {224, 208, 192, 128, 64};   // 256 rows need > 256 VGPRs with double-buffered fragments (spills)
+  for (int rows : cand) {
+    if (rows == 208 && !allow_half) continue;
+    int64_t tiles = ((M + rows - 1) / rows) * ntn;
     int64_t rounds = (tiles + 255) / 256;
-    double c = (double)rounds * (mb + 0.35);
-    if (c < bestc) { bestc = c; best = mb; }
+    double c = (double)rounds * (rows / 32.0 + 0.35);
+    if (c < bestc) { bestc = c; best = rows; }
   }
   return best;
 }
@@ -672,9 +694,9 @@ bool use_wide_tiles(int64_t M, int N) {
   return env && N % 256 == 0 && M * (int64_t)(N / 256) >= min_rows;
 }
 
-template <int MB>
+template <int ROWS>
 static int launch_linear_wide(LinearParams p, hipStream_t st) {
-  using T = TileW<MB>;
+  using T = TileW<ROWS>;
   p.mt_count = (int)((p.M + T::BM - 1) / T::BM); p.nt_count = p.N / 256;
   return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
@@ -684,11 +706,12 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
   if (p.M <= 0) return MMF_OK;
   if (use_wide_tiles(p.M, p.N)) {
-    switch (pick_wide_mb(p.M, p.N / 256)) {
-      case 2: return launch_linear_wide<2>(p, st);
-      case 4: return launch_linear_wide<4>(p, st);
-      case 6: return launch_linear_wide<6>(p, st);
-      default: return launch_linear_wide<7>(p, st);
+    switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0)) {
+      case 64: return launch_linear_wide<64>(p, st);
+      case 128: return launch_linear_wide<128>(p, st);
+      case 192: return launch_linear_wide<192>(p, st);
+      case 208: return launch_linear_wide<208>(p, st);
+      default: return launch_linear_wide<224>(p, st);
     }
   }
   if (use_big_tiles(p.M, p.N)) {

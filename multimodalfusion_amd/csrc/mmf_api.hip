@@ -82,7 +82,7 @@ constexpr int PREP_GROUPS = 512;
 
 struct AmilWs {
   float *M_step, *dM_step;           // [H] each: pooled embedding and its gradient inside mmf_amil_nll_step
-  unsigned long long* relu_bits;     // [ceil(N/32)][H/32][16]: h > 0 per element (LinearParams::relu_bits)
+  unsigned long long* relu_bits;     // [ceil(N/16)][H/32][8]: h > 0 per element (LinearParams::relu_bits)
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
   int parts, groups, splits, k_per_split, mstk, tile;
@@ -141,7 +141,7 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
     w.bytes = off;
     return w;
   }
-  w.relu_bits = reinterpret_cast<unsigned long long*>(take((size_t)((N + 31) / 32) * (H / 32) * 16 * 2));
+  w.relu_bits = reinterpret_cast<unsigned long long*>(take((size_t)((N + 15) / 16 + 2) * (H / 32) * 8 * 2));
   w.a = take((size_t)N * D);
   w.b = take(gated ? (size_t)N * D : 0);
   w.p = take((size_t)N);
@@ -246,7 +246,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 7; }
+int mmf_abi_version(void) { return 8; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -284,6 +284,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
   lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   lp.relu_bits = infer ? nullptr : w.relu_bits;
+  lp.allow_half = 1;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
@@ -339,10 +340,11 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.relu_bits = w.relu_bits;
+  dp.allow_half = 1;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
-  int dbc_groups = bwd_dh_fused_groups(d->N, d->H);
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, 1);
   if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
     dp.fused_prep = 1;
     dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;

@@ -47,6 +47,11 @@ struct Tile {
   static constexpr bool A_KCONTIG = A_KCONTIG_, B_KCONTIG = B_KCONTIG_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
+  // HALF: the wave's rows end with a 16-row HALF block (BM / WM = 32 MB + 16), multiplied on v_mfma_f32_16x16x4_f32
+  // (same FLOP per cycle as the 32x32x2 instruction).  208-row tiles = 6.5 blocks put a 50k bag on 241 of 256 CUs
+  // instead of 224 (195 rows per CU would be ideal; 192-row tiles need 261 workgroups = two rounds).
+  static constexpr bool HALF = (BM / WM) % 32 == 16;
+  static_assert(!HALF || (WM_ == 1 && A_KCONTIG_ && !BF16_ && G_ == 4), "half blocks: one wave row, k-contiguous A, fp32");
   static constexpr int A_STRIDE = A_KCONTIG ? KSTR : BM;
   static constexpr int B_STRIDE = B_KCONTIG ? KSTR : BN;
   static constexpr int A_FLOATS = A_KCONTIG ? BM * KSTR : KC * BM;
@@ -58,7 +63,7 @@ struct Tile {
   // ds_read_b128 / ds_read_b64 per k replaces 4 / 2 ds_read_b32 (the TN loop issued 192 LDS reads per 128 MFMAs).
   // Block mb / nb then holds rows 4 i + mb / columns 2 j + nb of the wave's 128 x 64 patch: see tn_store().
   static constexpr bool PERM = !A_KCONTIG_ && !B_KCONTIG_ && BM_ / WM_ == 128 && BN_ / WN_ == 64;
-  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be a multiple of 32x32");
+  static_assert((BM % (WM * 32) == 0 || HALF) && BN % (WN * 32) == 0, "wave tile must be a multiple of 32x32 (+ a half block)");
 };
 
 // thread -> (row, 16-byte column) maps of one staged chunk --------------------------------
@@ -309,6 +314,44 @@ __device__ inline void mfma_part(const FragA<T>& fa, const FragB<T>& fb, int lo,
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.v[mb - lo][j], fb.v[nb][j], acc[mb][nb], 0, 0, 0);
 }
 
+// ---- half block (Tile::HALF): rows 32 MB .. 32 MB + 15 of the wave's rows on v_mfma_f32_16x16x4_f32 ---------------
+// Operand layout of that instruction: lane (i = lane & 15, kq = lane >> 4) supplies A[i][k_kq] and B[k_kq][j = i];
+// D[i][j]: lane holds column j = lane & 15, rows 4 (lane >> 4) + reg.  Inside a fragment group of 8 k-values MFMA t
+// (t = 0, 1) contracts k = 8 g + 2 kq + t, so a lane's two A values are adjacent in the k-contiguous image (one
+// ds_read_b64, conflict-free with the KC + 4 pad: 16 rows x stride 36 words + 2 kq words hit 64 distinct banks).
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <class T>
+struct FragH { float a[2]; float b[T::NB][2][2]; };     // b[nb][column half c][t]
+template <class T>
+__device__ inline void read_half(const float* __restrict__ As, const float* __restrict__ Bs, int g, int arow_h, int brow0,
+                                 int lane, FragH<T>& f) {
+  const int i16 = lane & 15, kq = lane >> 4;
+  const float2 ta = ld2(As + (arow_h + i16) * KSTR + 8 * g + 2 * kq);
+  f.a[0] = ta.x; f.a[1] = ta.y;
+#pragma unroll
+  for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if constexpr (T::B_KCONTIG) {
+        const float2 tb = ld2(Bs + (brow0 + nb * 32 + 16 * c + i16) * KSTR + 8 * g + 2 * kq);
+        f.b[nb][c][0] = tb.x; f.b[nb][c][1] = tb.y;
+      } else {
+        f.b[nb][c][0] = Bs[(8 * g + 2 * kq) * T::BN + brow0 + nb * 32 + 16 * c + i16];
+        f.b[nb][c][1] = Bs[(8 * g + 2 * kq + 1) * T::BN + brow0 + nb * 32 + 16 * c + i16];
+      }
+    }
+}
+template <class T>
+__device__ inline void mfma_half(const FragH<T>& f, f32x4acc (&acch)[T::NB][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acch[nb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[t], f.b[nb][c][t], acch[nb][c], 0, 0, 0);
+}
+
 // `hook(s)` (s = 0..NS-1, chunk_steps<T>()) runs in front of the MFMA block of step s: the main loop uses it
 // to spread the staging of the NEXT chunk through this chunk's MFMA stream (global loads in the first half, LDS
 // writes in the second) instead of bursting it between two MFMA blocks, where the VMEM issue (throttled by the
@@ -318,7 +361,8 @@ constexpr int chunk_steps() { return (KC / (2 * T::G)) * (T::MB > 4 ? 2 : 1); }
 
 template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
-                                     f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook) {
+                                     f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook,
+                                     f32x4acc (*acch)[2] = nullptr) {
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + (T::PERM ? 4 * r : r);
   const int brow = wn * T::NB * 32 + (T::PERM ? 2 * r : r);
@@ -329,6 +373,8 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
   constexpr int PER_Q = NS / 4;
   FragA<T> fa[2];
   FragB<T> fb[2];
+  FragH<T> fh;
+  const int arow_h = wm * (T::BM / T::WM) + T::MB * 32, brow0 = wn * T::NB * 32;
 #ifdef MMF_DIAG_NOFRAG       /* diagnostic build: fragments read once per chunk only (results are wrong) */
   read_b<T>(Bs, 0, brow, hh, fb[0]); read_b<T>(Bs, 1, brow, hh, fb[1]);
   read_a<T>(As, 0, 0, MBH, arow, hh, fa[0]); read_a<T>(As, 1, 0, MBH, arow, hh, fa[1]);
@@ -347,12 +393,18 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
       read_a<T>(As, g1, part1 == 0 ? 0 : MBH, part1 == 0 ? MBH : T::MB, arow, hh, fa[(s + 1) & 1]);
     }
 #endif
+    if constexpr (T::HALF) {                     // the half block's fragments: read in the first part of group g,
+      if (part == 0) read_half<T>(As, Bs, g, arow_h, brow0, lane, fh);   // multiplied behind its last part
+    }
     hook(s);
 #ifndef MMF_DIAG_NOSCHED
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef MMF_DIAG_NOMFMA      /* diagnostic builds (tools/diag_build.py): timing only, results are wrong */
     mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
+    if constexpr (T::HALF) {
+      if (part == NP - 1) mfma_half<T>(fh, *reinterpret_cast<f32x4acc (*)[T::NB][2]>(acch));
+    }
 #endif
 #ifndef MMF_DIAG_NOSCHED
     __builtin_amdgcn_sched_barrier(0);
@@ -388,7 +440,8 @@ __device__ inline unsigned long long stamp_now() {
 // kt+1 (requested one chunk earlier) in quarters 0 / 1 and requests chunk kt+2 in quarters 2 / 3.  Pays only where
 // the staging path holds real VALU work (K-dh builds its A operand there: -3 us); plain copies got slower.
 template <class T, class LA, class LB, bool DEPHASE = false>
-__device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
+__device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB],
+                                     f32x4acc (*acch)[2] = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
 #pragma unroll
@@ -397,6 +450,14 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     for (int nb = 0; nb < T::NB; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  if constexpr (T::HALF) {
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acch[nb][c][i] = 0.f;
+  }
   if (nk <= 0) return;
 #if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
   unsigned long long s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0;
@@ -465,7 +526,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
       else if (q == 1) lb.load(kt + 1);
       else if (q == 2) la.store(nxt);
       else lb.store(nxt + T::A_FLOATS);
-    });
+    }, acch);
     MMF_STAMP(t2);
     MMF_STAMP(t3);
 #ifndef MMF_DIAG_NOBAR        /* diagnostic build: no barrier between chunks (results are wrong) */
@@ -617,6 +678,21 @@ __device__ inline void transpose_block(const f32x16& a, float* blk, int lane, fl
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int t = 0; t < 4; ++t) out[t] = ld4(blk + (rr + 8 * t) * EPI_STRIDE + 4 * c4);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// the half block of one column block: two 16x16 accumulators (columns 16 c .. 16 c + 15) -> 2 float4 per lane
+// (row rr + 8 t of the half block's 16 rows, columns 4*c4 .. 4*c4+3), via the wave's scratch
+__device__ inline void transpose_half(const f32x4acc& c0, const f32x4acc& c1, float* blk, int lane, float4 (&out)[2]) {
+  const int j = lane & 15, q = lane >> 4, rr = lane >> 3, c4 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    blk[(4 * q + i) * EPI_STRIDE + j] = c0[i];
+    blk[(4 * q + i) * EPI_STRIDE + 16 + j] = c1[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 2; ++t) out[t] = ld4(blk + (rr + 8 * t) * EPI_STRIDE + 4 * c4);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 

@@ -24,10 +24,12 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   const uint32_t* seed_dev;   // optional device-resident seed added to every key (graph-replay-safe dropout), or null
   int mt_count, nt_count;
   // optional: one bit per output element, y > 0 (relu'(u) . keep), for K-dh's epilogue -- which then does not have to
-  // read h a second time.  Layout: per 32x32 block (row block rb = row / 32, column block cb = col / 32) 16 words of
-  // 64 bits, word 4 t + e = wave ballot over the row-major epilogue lanes (lane = 8 rr + c4 holds row rr + 8 t,
-  // column 4 c4 + e of the block): bits[(rb * (N / 32) + cb) * 16 + 4 t + e].  Needs N % 32 == 0.
+  // read h a second time.  Layout: per 16x32 block (rb16 = row / 16, cb = col / 32) 8 words of 64 bits; a word is a
+  // wave ballot over the row-major epilogue lanes (lane = 8 rr + c4 holds row rr + 8 t, columns 4 c4 + e of a 32- or
+  // 16-row block): rows rr + 8 t with t = 0, 1 go to bit block rb16 as word 4 t + e, t = 2, 3 to rb16 + 1 as word
+  // 4 (t - 2) + e.  bits[(rb16 * (N / 32) + cb) * 8 + word].  Needs N % 32 == 0 and tile rows that are multiples of 16.
   unsigned long long* relu_bits;
+  int allow_half;          // 1: the 208-row half-block tile may be chosen (the stack's projection; off for generic callers)
   int deep;                // set by launch_linear: short grid, use the deep-prefetch main loop
 };
 
@@ -160,6 +162,7 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
   int mt_count, nt_count;
   int deep;                // set by launch_bwd_dh: short grid, deep-prefetch main loop (dh_mainloop_deep)
+  int allow_half;          // 1: the 208-row half-block tile may be chosen (needs fused_prep and relu_bits)
   // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
   // in LDS for its loader / epilogue and publishes them for the TN kernel
   int fused_prep;
@@ -217,10 +220,10 @@ int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A
 int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
-int bwd_dh_fused_groups(int64_t N, int H);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
-int pick_wide_mb(int64_t M, int ntn);
+int pick_wide_rows(int64_t M, int ntn, bool allow_half);
 bool use_wide_tiles(int64_t M, int N);
 // split-K plan shared by the workspace carving and the launcher
 int tn_tile_dim(int64_t K, int D_gate);                    // 256: one 8-wave 256x256 workgroup per CU; else 128
