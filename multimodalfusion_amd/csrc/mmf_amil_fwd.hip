@@ -75,6 +75,8 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
         else if constexpr (ACT < 0) y[e] = apply_act(y[e], p.act);
         if constexpr (DROP) y[e] = keep(dkey, idx + e, thr) ? y[e] * scale : 0.f;
       }
+      // (Tried: taking these ballots in K-gate's A loader instead, where h streams through staging registers anyway.
+      // The projection got 2 us back, K-gate lost 11: its first-column tiles became the launch's critical path.)
       if (p.relu_bits) {                     // wave-uniform; the ballots are taken by every lane, valid or not
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
