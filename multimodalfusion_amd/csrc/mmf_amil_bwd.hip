@@ -719,14 +719,14 @@ __device__ inline void tn_store(const TnProblem& q, int split, int tn, f32x16 (&
 
 template <class T, bool GATED, int DROP>
 __device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q, LoadM<T::BN, T::NT>& lb, int split, int tm,
-                                    int tn, int kbase, int kmax, int nk, bool do_sum, float* lds) {
+                                    int tn, int kbase, int kmax, int nk, int last_groups, bool do_sum, float* lds) {
   using LA = LoadA_M_Gate<T::BM, T::NT, GATED, DROP>;
   constexpr int DT = LA::DT;
   const int D = p.g.D, d0 = tm * DT;
   LA la;
   la.init(p.g, d0, kbase, kmax, do_sum);
   f32x16 acc[T::MB][T::NB];
-  gemm_mainloop<T>(la, lb, nk, lds, acc);
+  gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
   tn_store<T>(q, split, tn, acc, lds, [&](int r) {      // tile row -> row of the stacked [dWa ; dWb] slab
     const int half = r / DT, d = d0 + r - half * DT;
     return d < D ? half * D + d : -1;
@@ -766,6 +766,10 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   const int kbase = (int)(kb64 < p.K ? kb64 : p.K);
   const int kmax = (int)((kb64 + q.k_per_split) < p.K ? (kb64 + q.k_per_split) : p.K);
   const int nk = (kmax - kbase + KC - 1) / KC;
+  // fragment groups (2 G instances each) of the last chunk that hold data: splits are cut at multiples of 4 instances,
+  // not of whole chunks, so that all of them have the same length (50k bag: 42 x 1192 = 37.25 chunks each, where whole
+  // chunks gave 41 x 38 + one split of 4.5)
+  const int last_groups = nk > 0 ? ((kmax - kbase) - (nk - 1) * KC + 2 * T::G - 1) / (2 * T::G) : 0;
   const bool do_sum = tn == 0 && q.colsum != nullptr;
 #ifdef MMF_STAMPS             /* workgroup life time by tile kind: [0] sum plain, [1] sum gate, [2] count plain, [3] count gate */
   struct TnLife {
@@ -783,14 +787,14 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
     LoadA_M_Plain<T::BM, T::NT> la;
     la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
     f32x16 acc[T::MB][T::NB];
-    gemm_mainloop<T>(la, lb, nk, lds, acc);
+    gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
     tn_store<T>(q, split, tn, acc, lds, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
     if (do_sum)
       colsum_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
   } else if (p.g.gated) {
-    tn_gate_tile<T, true, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
+    tn_gate_tile<T, true, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, last_groups, do_sum, lds);
   } else {
-    tn_gate_tile<T, false, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, do_sum, lds);
+    tn_gate_tile<T, false, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, last_groups, do_sum, lds);
   }
 }
 
@@ -1011,14 +1015,14 @@ static int launch_tn_grid(const TnParams& p, int grid, hipStream_t st) {
 
 template <class T>
 static int launch_tn_t(TnParams p, hipStream_t st) {
-  if (p.k_per_split % KC != 0 || p.splits < 1) return MMF_ERR_ARG;
+  if (p.k_per_split % 4 != 0 || p.splits < 1) return MMF_ERR_ARG;
   int tiles = 0, blocks = 0;
   for (int i = 0; i < p.nprob; ++i) {
     TnProblem& q = p.prob[i];
     if (q.Ncols % 4 != 0 || q.ldb % 4 != 0 || q.M % 4 != 0) return MMF_ERR_SHAPE;
     if (q.kind == TN_A_PLAIN && q.lda % 4 != 0) return MMF_ERR_SHAPE;
     if (q.splits <= 0) { q.splits = p.splits; q.k_per_split = p.k_per_split; }
-    if (q.k_per_split % KC != 0 || q.k_per_split < KC) return MMF_ERR_ARG;
+    if (q.k_per_split % 4 != 0 || q.k_per_split < 4) return MMF_ERR_ARG;
     if (q.kind == TN_A_GATE) {
       const int dt = p.g.gated ? T::BM / 2 : T::BM;      // attention dims per tile (both halves together when gated)
       q.tiles_m = (p.g.D + dt - 1) / dt;

@@ -107,9 +107,11 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   int splits = tn_splits(N, tiles, td);
   w.tile = td;
   w.splits = splits;
+  // splits are cut at multiples of 4 instances (one MFMA k-step of the TN tile), not of whole 32-instance chunks: all
+  // splits then have the same length and end with a partial chunk whose empty fragment groups are skipped
   int64_t kps = (N + splits - 1) / splits;
-  w.k_per_split = (int)((kps + KC - 1) / KC * KC);
-  if (w.k_per_split < KC) w.k_per_split = KC;
+  w.k_per_split = (int)((kps + 3) / 4 * 4);
+  if (w.k_per_split < 4) w.k_per_split = 4;
   // A gate tile builds its A operand (dP from a, b, ds) in the staging path and lives ~8 % longer per K row than a
   // dW1 tile (stamps: 710 k vs 659 k cycles with equal splits), so the whole launch waited for the gate tiles.  The
   // workgroups the uniform split leaves over (256 - 6 x 42 = 4) go to the gate problem: 44 splits of 36 chunks beside
@@ -127,8 +129,8 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
     }
     if (env > 0) sg = env;
     const int64_t kg = (N + sg - 1) / sg;
-    int kpg = (int)((kg + KC - 1) / KC * KC);
-    if (kpg < KC) kpg = KC;
+    int kpg = (int)((kg + 3) / 4 * 4);
+    if (kpg < 4) kpg = 4;
     w.splits_g = sg; w.k_per_split_g = kpg;
   }
   w.M_step = take(H);
@@ -632,8 +634,8 @@ static AttnWs carve_attn(void* base, int64_t N, int H, int D, int gated) {
   const int tiles = ((D + dt - 1) / dt) * ((H + td - 1) / td);
   w.splits = tn_splits(N, tiles, td);
   const int64_t kps = (N + w.splits - 1) / w.splits;
-  w.k_per_split = (int)((kps + KC - 1) / KC * KC);
-  if (w.k_per_split < KC) w.k_per_split = KC;
+  w.k_per_split = (int)((kps + 3) / 4 * 4);
+  if (w.k_per_split < 4) w.k_per_split = 4;
   w.a = take((size_t)N * D);
   w.b = take(gated ? (size_t)N * D : 0);
   w.s_part = take((size_t)w.parts * N);
@@ -767,7 +769,7 @@ int mmf_linear_backward(const float* dy, const float* const* x_segs, int32_t nse
   TnParams tp{};
   tp.nprob = nseg; tp.K = M; tp.splits = splits; tp.tile = tn_tile_dim(M, 0);
   int64_t kps = (M + splits - 1) / splits;
-  tp.k_per_split = (int)((kps + KC - 1) / KC * KC);
+  tp.k_per_split = (int)((kps + 3) / 4 * 4);
   for (int i = 0; i < nseg; ++i) {
     if (!x_segs[i]) return MMF_ERR_ARG;
     TnProblem& q = tp.prob[i];

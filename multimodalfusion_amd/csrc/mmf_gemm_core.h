@@ -362,7 +362,7 @@ constexpr int chunk_steps() { return (KC / (2 * T::G)) * (T::MB > 4 ? 2 : 1); }
 template <class T, class Hook>
 __device__ inline void compute_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                      f32x16 (&acc)[T::MB][T::NB], int wm, int wn, int lane, Hook&& hook,
-                                     f32x4acc (*acch)[2] = nullptr) {
+                                     f32x4acc (*acch)[2] = nullptr, int ng_valid = 1 << 30) {
   const int r = lane & 31, hh = lane >> 5;
   const int arow = wm * T::MB * 32 + (T::PERM ? 4 * r : r);
   const int brow = wn * T::NB * 32 + (T::PERM ? 2 * r : r);
@@ -401,7 +401,9 @@ __device__ inline void compute_chunk(const float* __restrict__ As, const float* 
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef MMF_DIAG_NOMFMA      /* diagnostic builds (tools/diag_build.py): timing only, results are wrong */
-    mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
+    // ng_valid: fragment groups of this chunk that hold data (split-K launches cut K at multiples of 4 instances, so
+    // every workgroup's LAST chunk is partly zero fill); one scalar branch per step, same registers as without it
+    if (g < ng_valid) mfma_part<T>(fa[s & 1], fb[g & 1], lo, hi, acc);
     if constexpr (T::HALF) {
       if (part == NP - 1) mfma_half<T>(fh, *reinterpret_cast<f32x4acc (*)[T::NB][2]>(acch));
     }
@@ -441,7 +443,7 @@ __device__ inline unsigned long long stamp_now() {
 // the staging path holds real VALU work (K-dh builds its A operand there: -3 us); plain copies got slower.
 template <class T, class LA, class LB, bool DEPHASE = false>
 __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB],
-                                     f32x4acc (*acch)[2] = nullptr) {
+                                     f32x4acc (*acch)[2] = nullptr, int last_groups = 1 << 30) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
 #pragma unroll
@@ -484,6 +486,9 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     const bool more2 = kt + 2 < nk;
     MMF_STAMP(t0);
     MMF_STAMP(t1);
+    // a K range that ends inside its last chunk: only the first `last_groups` fragment groups of that chunk hold data,
+    // the rest is zero fill -- and multiplying zeros costs what multiplying data costs (see compute_chunk: ng_valid)
+    const int ng_valid = more ? (1 << 30) : last_groups;
     compute_chunk<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
       if (!more) return;
 #ifdef MMF_DIAG_NOLOAD
@@ -526,7 +531,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
       else if (q == 1) lb.load(kt + 1);
       else if (q == 2) la.store(nxt);
       else lb.store(nxt + T::A_FLOATS);
-    }, acch);
+    }, acch, ng_valid);
     MMF_STAMP(t2);
     MMF_STAMP(t3);
 #ifndef MMF_DIAG_NOBAR        /* diagnostic build: no barrier between chunks (results are wrong) */
