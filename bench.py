@@ -90,12 +90,16 @@ def build_model(dev, eval_mode):
     return model
 
 
+def flat_size(model):
+    from multimodalfusion_amd.dp import flat_layout
+    return flat_layout(list(model.parameters()))[1]
+
+
 def flat_views(model, flat):
-    off, views = 0, []
-    for p in model.parameters():
-        views.append(flat[off:off + p.numel()].view_as(p))
-        off += p.numel()
-    return views
+    """Per-parameter views of a flat gradient buffer (multimodalfusion_amd.dp.flat_layout: 16-byte aligned tensors)."""
+    from multimodalfusion_amd.dp import flat_layout
+    params = list(model.parameters())
+    return [flat[off:off + p.numel()].view_as(p) for p, off in zip(params, flat_layout(params)[0])]
 
 
 def make_step(model, x, dev, flat=None, world=1, autograd=False):
@@ -110,7 +114,7 @@ def make_step(model, x, dev, flat=None, world=1, autograd=False):
     if not autograd:
         # the one-call step: gradients of loss / world are WRITTEN (not accumulated) into the flat buffer
         if flat is None:
-            flat = torch.empty(sum(p.numel() for p in params), device=dev)
+            flat = torch.empty(flat_size(model), device=dev)
         views = flat_views(model, flat)
 
         def fused():
@@ -413,7 +417,7 @@ def h2d_leg(model, N, dev, steps, warmup, bf16=False):
     loss_fn = NLLSurvLoss(alpha=0.0)
     Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
 
-    flat = torch.empty(sum(p.numel() for p in model.parameters()), device=dev)
+    flat = torch.empty(flat_size(model), device=dev)
     views = flat_views(model, flat)
 
     def run(x):
@@ -524,12 +528,9 @@ def main():
     if world > 1:
         # flat fp32 gradient buffer; every p.grad is a view into it, so backward accumulates in place and the
         # step needs exactly one all-reduce
-        n_el = sum(p.numel() for p in model.parameters())
-        flat = torch.zeros(n_el, device=dev)
-        off = 0
-        for p in model.parameters():
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        flat = torch.zeros(flat_size(model), device=dev)
+        for p, v in zip(model.parameters(), flat_views(model, flat)):
+            p.grad = v
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     x = torch.randn(N, 1024, device=dev, generator=g)      # synthetic bag, resident in HBM

@@ -15,21 +15,32 @@ import torch
 import torch.distributed as dist
 
 
+def flat_layout(params, align: int = 4):
+    """Offsets (in elements) of `params` inside ONE flat fp32 buffer, every tensor starting on a 16-byte boundary
+    (the kernels take parameters and write gradients with 16-byte vector accesses; a 1-element tensor such as
+    attention_c.bias would otherwise misalign everything behind it), and the buffer's total length.  The padding
+    elements are zero and stay zero (zero weight, zero gradient => zero Adam update).  Shared by optim.FlatAdam,
+    FlatGradBuffer and pipeline.BagsInFlight, whose buffers are added to / copied into each other."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    return offs, off
+
+
 class FlatGradBuffer:
     """Makes every parameter's .grad a view into one contiguous buffer, so a step needs one collective."""
 
     def __init__(self, model: torch.nn.Module):
         self.params = [p for p in model.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        offs, n = flat_layout(self.params)
         dev = self.params[0].device
         # [n gradients | 2 control words]: the control words travel in the same collective (utils/core_utils.py)
         self.bucket = torch.zeros(n + 2, dtype=torch.float32, device=dev)
         self.flat = self.bucket[:n]
         self.tail = self.bucket[n:]
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, offs):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def zero(self):
         self.bucket.zero_()

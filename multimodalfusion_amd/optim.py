@@ -24,9 +24,10 @@ class FlatAdam:
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        from .dp import flat_layout
+        offs, n = flat_layout(self.params)            # every tensor on a 16-byte boundary, zero padding between
         self.n = n
-        self.flat_w = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_w = torch.zeros(n, dtype=torch.float32, device=dev)
         # gradient bucket: [n gradients | 2 control words].  The control words ride along in the one all-reduce of a
         # data-parallel step (utils/core_utils.py: "did the window's last bag run" and "bags kept in the window").
         self.bucket = torch.zeros(n + 2, dtype=torch.float32, device=dev)
@@ -35,18 +36,18 @@ class FlatAdam:
         self.l1_mask = None
         if l1_modules is not None:
             chosen = {id(p) for m in l1_modules for p in m.parameters()}
-            self.l1_mask = torch.cat([torch.full((p.numel(),), 1.0 if id(p) in chosen else 0.0, device=dev)
-                                      for p in self.params])
+            self.l1_mask = torch.zeros(n, dtype=torch.float32, device=dev)
+            for p, off in zip(self.params, offs):
+                if id(p) in chosen:
+                    self.l1_mask[off:off + p.numel()] = 1.0
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
         with torch.no_grad():
-            for p in self.params:          # parameters (and grads) become views of the flat buffers
+            for p, off in zip(self.params, offs):          # parameters (and grads) become views of the flat buffers
                 k = p.numel()
                 self.flat_w[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_w[off:off + k].view_as(p)
                 p.grad = self.flat_g[off:off + k].view_as(p)
-                off += k
         self.lr, self.wd, self.betas, self.eps, self.lambda_l1 = lr, weight_decay, betas, eps, lambda_l1
         self.t = 0
         self._partials = torch.empty(512, dtype=torch.float32, device=dev)

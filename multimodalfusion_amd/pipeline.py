@@ -23,10 +23,12 @@ class BagsInFlight:
         self.device = self.params[0].device if device is None else torch.device(device)
         self.n = max(1, int(n_streams))
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
-        numel = sum(p.numel() for p in self.params)
-        # rows padded to 16 bytes: the kernels of the one-call step store float4s into the slot views
-        self._rows = torch.zeros((self.n, (numel + 3) // 4 * 4), dtype=torch.float32, device=self.device)
-        self.slots = [self._rows[k, :numel] for k in range(self.n)]
+        from .dp import flat_layout
+        # the layout of optim.FlatAdam / dp.FlatGradBuffer (every tensor on a 16-byte boundary): slots are summed into
+        # those buffers, and the kernels of the one-call step store float4s into the slot views
+        self._offs, numel = flat_layout(self.params)
+        self._rows = torch.zeros((self.n, numel), dtype=torch.float32, device=self.device)
+        self.slots = [self._rows[k] for k in range(self.n)]
         self._count = 0
         self._views = None
         self._used = [False] * self.n
@@ -54,11 +56,12 @@ class BagsInFlight:
         with torch.cuda.stream(st):
             loss = loss_fn_of_model_call()
             grads = torch.autograd.grad(loss, self.params)
-            pieces = [g.reshape(-1) for g in grads]
+            dst = [self.slots[i][off:off + p.numel()] for p, off in zip(self.params, self._offs)]
+            src = [g.reshape(-1) for g in grads]
             if accumulate and self._used[i]:
-                self.slots[i].add_(torch.cat(pieces))
+                torch._foreach_add_(dst, src)                 # one multi-tensor launch
             else:
-                torch.cat(pieces, out=self.slots[i])          # straight into the slot: one launch
+                torch._foreach_copy_(dst, src)
             self._used[i] = True
         return loss
 
@@ -76,11 +79,8 @@ class BagsInFlight:
         if self._views is None:
             self._views = []
             for k in range(self.n):
-                off, vs = 0, []
-                for p in self.params:
-                    vs.append(self.slots[k][off:off + p.numel()].view_as(p))
-                    off += p.numel()
-                self._views.append(vs)
+                self._views.append([self.slots[k][off:off + p.numel()].view_as(p)
+                                    for p, off in zip(self.params, self._offs)])
         with torch.cuda.stream(st):
             out = model.nll_step(bag, label, c, alpha=alpha, loss_scale=loss_scale, grad_out=self._views[i],
                                  accumulate=accumulate and self._used[i])
@@ -123,7 +123,5 @@ class BagsInFlight:
             s.wait_stream(cur)
 
     def assign_grads(self, flat: torch.Tensor):
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self._offs):
             p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()

@@ -86,15 +86,24 @@ def test_dp2_equals_gc2():
 
 
 def test_flat_buffer_views():
-    model = _model()
+    from multimodalfusion_amd.dp import flat_layout
+    torch.manual_seed(3)
+    # odd-sized tensors (a [1 x 7] scorer and its 1-element bias, as attention_c has) must not misalign what follows
+    model = torch.nn.Sequential(torch.nn.Linear(16, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1), torch.nn.Linear(1, 4))
     buf = FlatGradBuffer(model)
-    _loss(model, _bags()[0]).backward()
-    off = 0
-    for p in model.parameters():
+    params = list(model.parameters())
+    offs, total = flat_layout(params)
+    assert total == buf.flat.numel() and all(o % 4 == 0 for o in offs)
+    torch.sigmoid(model(_bags()[0])).mean(0).pow(2).sum().backward()
+    for p, off in zip(params, offs):
         assert p.grad.data_ptr() == buf.flat.data_ptr() + 4 * off     # grads accumulate in place in the flat buffer
+        assert p.grad.data_ptr() % 16 == 0
         assert torch.equal(buf.flat[off:off + p.numel()].view_as(p), p.grad)
-        off += p.numel()
     assert float(buf.flat.abs().sum()) > 0
+    used = torch.zeros_like(buf.flat, dtype=torch.bool)
+    for p, off in zip(params, offs):
+        used[off:off + p.numel()] = True
+    assert float(buf.flat[~used].abs().sum()) == 0                    # the padding stays zero
     buf.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
 

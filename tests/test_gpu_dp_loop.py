@@ -91,4 +91,5 @@ def test_inflight_loop_equals_sequential_loop():
     a, sa = _run(dp=False, gc=2, inflight=1)
     b, sb = _run(dp=False, gc=2, inflight=2)
     assert sa == sb
-    np.testing.assert_allclose(b, a, rtol=1e-6, atol=1e-8)
+    # atol: attention_c.bias has an analytically zero gradient; Adam turns its rounding noise into +-lr-sized steps
+    np.testing.assert_allclose(b, a, rtol=1e-6, atol=5e-7)

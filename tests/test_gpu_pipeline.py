@@ -26,6 +26,14 @@ def test_bags_in_flight_match_sequential(n_streams):
     ys = [torch.tensor([i % 4], device=DEV) for i in range(len(bags))]
     c = torch.tensor([0.0], device=DEV)
     params = [p for p in model.parameters()]
+    from multimodalfusion_amd.dp import flat_layout
+    offs, total_len = flat_layout(params)       # the slots' layout: every tensor on a 16-byte boundary, zero padding
+
+    def pack(grads):
+        flat = torch.zeros(total_len, device=DEV)
+        for g, p, off in zip(grads, params, offs):
+            flat[off:off + p.numel()] = g.reshape(-1)
+        return flat
 
     def loss_of(i):
         hz, S, _, _ = model(path_features=bags[i])
@@ -35,7 +43,7 @@ def test_bags_in_flight_match_sequential(n_streams):
     want, want_loss = [], []
     for i in range(len(bags)):
         l = loss_of(i)
-        want.append(torch.cat([g.reshape(-1) for g in torch.autograd.grad(l, params)]))
+        want.append(pack(torch.autograd.grad(l, params)))
         want_loss.append(l.detach())
     torch.cuda.synchronize()
 
