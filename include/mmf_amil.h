@@ -66,6 +66,12 @@ typedef struct mmf_amil_desc {
                               * By-value seeds are frozen into a captured hipGraph; a graph whose first node bumps this
                               * word draws fresh masks on every replay.  Forward and backward must see the same value. */
   struct mmf_trace* trace;   /* optional kernel trace (mmf_trace_create), or NULL: see "Kernel trace" below */
+  int32_t concurrent;        /* scheduling hint; results do not depend on it.  0: the call has the GPU to itself -- the
+                              * row-parallel GEMMs take the tile height that finishes ONE bag soonest (208 rows: a 50k
+                              * bag on 241 of 256 CUs, one bag per step 0.816 -> 0.801 ms).  1: other bags' kernels run
+                              * beside it on other streams (pipeline.BagsInFlight) -- 224-row tiles, which leave 32 CUs
+                              * to the neighbours, gave the higher aggregate rate in two of three same-run comparisons
+                              * (1376 vs 1337 bags/s with three bags in flight) and the same rate in the third. */
 } mmf_amil_desc;
 
 typedef struct mmf_amil_grads {

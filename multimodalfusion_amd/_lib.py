@@ -24,7 +24,7 @@ class AmilDesc(C.Structure):
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("Wa", C.c_void_p), ("ba", C.c_void_p),
         ("Wb", C.c_void_p), ("bb", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
         ("p_h", C.c_float), ("p_att", C.c_float), ("seed", C.c_uint32),
-        ("seed_dev", C.c_void_p), ("trace", C.c_void_p),
+        ("seed_dev", C.c_void_p), ("trace", C.c_void_p), ("concurrent", C.c_int32),
     ]
 
 

@@ -286,7 +286,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
   lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   lp.relu_bits = infer ? nullptr : w.relu_bits;
-  lp.allow_half = 1;
+  lp.allow_half = d->concurrent ? 0 : 1;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
@@ -342,11 +342,11 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.relu_bits = w.relu_bits;
-  dp.allow_half = 1;
+  dp.allow_half = d->concurrent ? 0 : 1;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
-  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, 1);
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1);
   if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
     dp.fused_prep = 1;
     dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;

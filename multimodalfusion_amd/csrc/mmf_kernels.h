@@ -29,7 +29,7 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   // 16-row block): rows rr + 8 t with t = 0, 1 go to bit block rb16 as word 4 t + e, t = 2, 3 to rb16 + 1 as word
   // 4 (t - 2) + e.  bits[(rb16 * (N / 32) + cb) * 8 + word].  Needs N % 32 == 0 and tile rows that are multiples of 16.
   unsigned long long* relu_bits;
-  int allow_half;          // 1: the 208-row half-block tile may be chosen (the stack's projection; off for generic callers)
+  int allow_half;          // 1: the 208-row half-block tile may be chosen (the stack's projection with mmf_amil_desc::concurrent == 0)
   int deep;                // set by launch_linear: short grid, use the deep-prefetch main loop
 };
 
@@ -162,7 +162,7 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
   int mt_count, nt_count;
   int deep;                // set by launch_bwd_dh: short grid, deep-prefetch main loop (dh_mainloop_deep)
-  int allow_half;          // 1: the 208-row half-block tile may be chosen (needs fused_prep and relu_bits)
+  int allow_half;          // 1: the 208-row half-block tile may be chosen (needs fused_prep, relu_bits, concurrent == 0)
   // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
   // in LDS for its loader / epilogue and publishes them for the TN kernel
   int fused_prep;

@@ -20,8 +20,16 @@ _drop_calls = 0
 #   _seed_word  a device int32 word added to every dropout seed (graph.DeviceSeed sets it while it captures / replays a
 #               hipGraph); each autograd node remembers the word its forward used, so its backward uses the same one;
 #   _trace      an mmf_trace handle (bench.py's roofline leg: per-kernel HIP-event timing on the launch stream).
+#   _concurrent scheduling hint (mmf_amil_desc::concurrent): pipeline.BagsInFlight raises it while it issues a bag.
 _seed_word = None
 _trace = None
+_concurrent = 0
+
+
+def set_concurrent(flag):
+    global _concurrent
+    prev, _concurrent = _concurrent, 1 if flag else 0
+    return prev
 
 
 def set_device_seed(word):
@@ -42,7 +50,7 @@ def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, se
                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF,
-                    seed_dev=ptr(seed_word), trace=_trace)
+                    seed_dev=ptr(seed_word), trace=_trace, concurrent=_concurrent)
 
 
 def next_dropout_seed() -> int:

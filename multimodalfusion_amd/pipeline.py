@@ -53,9 +53,15 @@ class BagsInFlight:
         for t in inputs:
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(st)
+        from . import ops
+        prev = ops.set_concurrent(self.n > 1)       # tile choice: leave CUs to the other bags' kernels
+        try:
+            with torch.cuda.stream(st):
+                loss = loss_fn_of_model_call()
+                grads = torch.autograd.grad(loss, self.params)
+        finally:
+            ops.set_concurrent(prev)
         with torch.cuda.stream(st):
-            loss = loss_fn_of_model_call()
-            grads = torch.autograd.grad(loss, self.params)
             dst = [self.slots[i][off:off + p.numel()] for p, off in zip(self.params, self._offs)]
             src = [g.reshape(-1) for g in grads]
             if accumulate and self._used[i]:
@@ -81,10 +87,15 @@ class BagsInFlight:
             for k in range(self.n):
                 self._views.append([self.slots[k][off:off + p.numel()].view_as(p)
                                     for p, off in zip(self.params, self._offs)])
-        with torch.cuda.stream(st):
-            out = model.nll_step(bag, label, c, alpha=alpha, loss_scale=loss_scale, grad_out=self._views[i],
-                                 accumulate=accumulate and self._used[i])
-            self._used[i] = True
+        from . import ops
+        prev = ops.set_concurrent(self.n > 1)       # tile choice: leave CUs to the other bags' kernels
+        try:
+            with torch.cuda.stream(st):
+                out = model.nll_step(bag, label, c, alpha=alpha, loss_scale=loss_scale, grad_out=self._views[i],
+                                     accumulate=accumulate and self._used[i])
+                self._used[i] = True
+        finally:
+            ops.set_concurrent(prev)
         return out
 
     def all_reduce_slot(self, group=None):
