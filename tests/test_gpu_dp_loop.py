@@ -47,16 +47,45 @@ def _run(dp, gc, inflight=1):
     return opt.flat_w.detach().cpu().numpy().copy(), steps
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, gc=1, inflight=1):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    w, steps = _run(dp=True, gc=1)
+    w, steps = _run(dp=True, gc=gc, inflight=inflight)
     q.put((rank, w, steps))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _spawn2(gc, inflight):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, gc, inflight)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, w, steps = q.get(timeout=300)
+        got[rank] = (w, steps)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_dp2_with_bags_in_flight_equals_gc4():
+    """DP-2 x local gc = 2 with the two bags of a rank's window on two HIP streams == single-process gc = 4."""
+    ref, ref_steps = _run(dp=False, gc=4)
+    got = _spawn2(gc=2, inflight=2)
+    assert got[0][1] == got[1][1] == ref_steps
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_allclose(got[0][0], ref, rtol=2e-5, atol=5e-7)
 
 
 def test_dp2_loop_on_the_gpu_equals_gc2():
