@@ -212,21 +212,20 @@ __global__ __launch_bounds__(T::NT) void gate_fwd_kernel(GateFwdParams p) {
   gate_fwd_tile<T, GATED>(p, lds, (int)p.row_begin + mt * T::BM, nt);
 }
 
-// Two tile heights in ONE launch: workgroups [0, grid_big) take TB-row tiles of rows [row_begin, row_split), the rest
-// take TS-row tiles of rows [row_split, row_end).  The short tiles are dispatched last and fill what would otherwise
-// be a sparse last round of tall tiles (see launch_gate_fwd).  TB and TS have the same thread count and column width.
+// Two tile heights in ONE launch: the bag's rows are cut into regions of tall (TB) or short (TS) tiles, taken by
+// consecutive ranges of workgroups (GateFwdParams::reg; launch_gate_fwd plans them).  TB and TS have the same thread
+// count and column width.
 template <class TB, class TS, bool GATED>
 __global__ __launch_bounds__(TB::NT) void gate_fwd_mixed_kernel(GateFwdParams p) {
   static_assert(TB::NT == TS::NT && TB::BN == TS::BN, "mixed tiles share the launch shape");
   extern __shared__ __align__(16) float lds[];
+  int r = 0;
+  for (int i = 1; i < p.nreg; ++i)
+    if ((int)blockIdx.x >= p.reg[i].grid_begin) r = i;
   int mt, nt;
-  if ((int)blockIdx.x < p.grid_big) {
-    if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
-    gate_fwd_tile<TB, GATED>(p, lds, (int)p.row_begin + mt * TB::BM, nt);
-  } else {
-    if (!tile_of_block(blockIdx.x - p.grid_big, p.mt_count2, p.nt_count, mt, nt)) return;
-    gate_fwd_tile<TS, GATED>(p, lds, (int)p.row_split + mt * TS::BM, nt);
-  }
+  if (!tile_of_block(blockIdx.x - p.reg[r].grid_begin, p.reg[r].mt_count, p.nt_count, mt, nt)) return;
+  if (p.reg[r].tall) gate_fwd_tile<TB, GATED>(p, lds, (int)p.reg[r].row0 + mt * TB::BM, nt);
+  else gate_fwd_tile<TS, GATED>(p, lds, (int)p.reg[r].row0 + mt * TS::BM, nt);
 }
 
 template <class T, bool GATED>
@@ -747,20 +746,44 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   };
   const bool big = (p.N / 128) * p.nt_count >= 256;
   if (!big) return small(p);
-  // 128x128 tiles run two per CU: 512 slots.  A 50k bag is 1564 tiles = 3 rounds + 28 tiles, and those 28 cost most
-  // of a 4th round (132 us against 116 us for the 1536 tiles of 49,152 rows).  The rows of such a sparse last round
-  // are cut into 64-row tiles of the same launch: twice as many CUs work on them and each finishes in half the time.
-  // (A separate second launch for them was tried first and cost the 16 us back in launch latency.)
+  // 128x128 tiles run two per CU: 512 slots.  Two things cost this launch time: a sparse last round (a 50k bag is
+  // 1564 tiles = 3 rounds + 28 tiles, which cost most of a 4th round: 132 us against 116 us for the 1536 tiles of
+  // 49,152 rows) and the two workgroups of a CU running IN PHASE -- both in their main loops, then both in their
+  // epilogues (tanh / sigmoid pairs, 64 KB of a, b stores each) with the MFMA pipe idle.  Both are answered by the
+  // ORDER and the HEIGHT of the tiles in one launch (workgroups start in block order as slots free up; the first 512
+  // start at once, the dispatcher placing one per CU before the second):
+  //   A  256 tall tiles          -> slot 1 of every CU, finishing at T, 2T, 3T ...
+  //   B  256 short (64-row) ones -> slot 2, finishing at T/2: from here on slot 2 runs half a tile out of phase
+  //   C  256 (2R - 2) tall tiles -> taken alternately by slot 2 (at T/2, 3T/2, ...) and slot 1 (at T, 2T, ...)
+  //   D  256 short tiles         -> slot 2's last, so that both slots end at R T
+  //   E  the remaining rows as short tiles (twice as many CUs work on them, each for half the time)
+  // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
   static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
   int64_t mt = (p.N + 127) / 128;
-  const int64_t slots = 512, total = mt * p.nt_count, rem = total % slots;
-  if (env_mixed && total > slots && rem > 0 && rem <= slots / 4 && slots % p.nt_count == 0) {
-    mt = (total - rem) / p.nt_count;
-    p.row_split = mt * 128;
-    p.mt_count = (int)mt;
-    p.mt_count2 = (int)((p.N - p.row_split + 63) / 64);
-    p.grid_big = grid_for_tiles(p.mt_count, p.nt_count);
-    const int grid = p.grid_big + grid_for_tiles(p.mt_count2, p.nt_count);
+  const int64_t slots = 512, total = mt * p.nt_count;
+  const int R = (int)(total / slots);
+  if (env_mixed && R >= 2 && slots % (2 * p.nt_count) == 0) {
+    const int half_m = (int)(slots / 2 / p.nt_count);          // m-tiles in a wave of 256 workgroups
+    int64_t row = 0;
+    int grid = 0, n = 0;
+    auto region = [&](int tall, int64_t m_tiles) {
+      if (m_tiles <= 0) return;
+      p.reg[n].row0 = row; p.reg[n].mt_count = (int)m_tiles; p.reg[n].grid_begin = grid; p.reg[n].tall = tall;
+      grid += grid_for_tiles((int)m_tiles, p.nt_count);
+      row += m_tiles * (tall ? 128 : 64);
+      ++n;
+    };
+    if (env_mixed == 2) {
+      const int64_t rem = total % slots;
+      region(1, (total - rem) / p.nt_count);
+    } else {
+      region(1, half_m);
+      region(0, half_m);
+      region(1, (int64_t)half_m * (2 * R - 2));
+      region(0, half_m);
+    }
+    region(0, (p.N - row + 63) / 64);
+    p.nreg = n;
     return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, true>, p, grid, st)
                    : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, false>, p, grid, st);
   }

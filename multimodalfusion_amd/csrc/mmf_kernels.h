@@ -45,8 +45,10 @@ struct GateFwdParams {
   const uint32_t* seed_dev;
   int mt_count, nt_count;
   int64_t row_begin, row_end;   // this launch's rows of the bag (set by launch_gate_fwd)
-  int64_t row_split;            // mixed launch: tall tiles cover [row_begin, row_split), short tiles [row_split, row_end)
-  int mt_count2, grid_big;      // mixed launch: short row tiles; workgroups of the tall part
+  // mixed launch (gate_fwd_mixed_kernel): up to 5 row regions in workgroup order, each of tall (128-row) or short
+  // (64-row) tiles
+  struct Region { int64_t row0; int mt_count, grid_begin, tall; } reg[5];
+  int nreg;
   int deep;                     // set by launch_gate_fwd: short grid, use the deep-prefetch main loop
 };
 
