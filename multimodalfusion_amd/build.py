@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmf_amil.so")
 OBJ = os.path.join(HERE, "_build")   # objects and -save-temps output (git- and gpurun-ignored)
 SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
-HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_gemm_dma.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h", "mmf_bf16.h",
+HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_gemm_split.h", "mmf_gemm_dma.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h", "mmf_bf16.h",
            os.path.join("..", "..", "include", "mmf_amil.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

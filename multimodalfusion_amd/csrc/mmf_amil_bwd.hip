@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "mmf_gemm_core.h"
+#include "mmf_gemm_split.h"
 #include "mmf_kernels.h"
 
 namespace mmf {
@@ -250,6 +251,170 @@ __device__ inline void dh_mainloop_deep(const LA& la0, const LB& lb0, int nk, fl
   }
 }
 
+// ---- the same operands for the split-operand core (mmf_gemm_split.h): chunks of 16 attention dims ------------------
+// Gated stacks with compiled-in switches only (MODE = 2 | dropout).  k order as LoadP_K: chunk 2j = d pre-tanh, chunk
+// 2j + 1 = d pre-sigmoid of dims 16 j .. 16 j + 15; the odd chunk reuses the even chunk's a, b, Wc registers.
+template <int ROWS, int NT, int MODE>
+struct SplitP_K {
+  static_assert(MODE >= 2, "gated, switches compiled in");
+  static constexpr bool DROP = (MODE & 1) != 0;
+  static constexpr int TOTAL = ROWS * 4, NV = (TOTAL + NT - 1) / NT;
+  static_assert(TOTAL >= NT, "tile too small for this thread count");
+  GateBwdCtx g;
+  rsrc_t ra, rb, rwc;
+  int row0, tid, d0;
+  uint32_t thr;
+  float dscale;
+  unsigned voff[NV];
+  float dsr[NV];
+  float4 ra4[NV], rb4[NV], wc4;
+  __device__ static inline int slot(int tid, int i) { const int idx = tid + i * NT; return idx < TOTAL ? idx : idx - NT; }
+  __device__ inline void init_common(const GateBwdCtx& g_, int row0_, int nrows) {
+    g = g_; g.resolve_seed(); row0 = row0_; tid = threadIdx.x;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    const unsigned bytes = (unsigned)nrows * (unsigned)g.D * 4u;
+    ra = make_rsrc(g.a, bytes);
+    rb = make_rsrc(g.b, bytes);
+    rwc = make_rsrc(g.Wc, (unsigned)g.D * 4u);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = slot(tid, i), rr = row0 + (idx >> 2);
+      voff[i] = rr < nrows ? ((unsigned)rr * (unsigned)g.D + 4u * (idx & 3)) * 4u : OOB;
+    }
+  }
+  __device__ inline void init(const GateBwdCtx& g_, int row0_, int nrows) {
+    init_common(g_, row0_, nrows);
+    rsrc_t rds = make_rsrc(g.ds, (unsigned)nrows * 4u);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int rr = row0 + (slot(tid, i) >> 2);
+      dsr[i] = bld1(rds, rr < nrows ? (unsigned)rr * 4u : OOB, 0);     // rows beyond the bag: ds = 0 => dP = 0
+    }
+  }
+  __device__ inline void init_lds(const GateBwdCtx& g_, int row0_, int nrows, const float* ds_lds) {
+    init_common(g_, row0_, nrows);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int rl = slot(tid, i) >> 2;
+      dsr[i] = row0 + rl < nrows ? ds_lds[rl] : 0.f;
+    }
+  }
+  __device__ inline void load_pair(int kt) {          // kt even: a, b, Wc of dims 8 kt .. 8 kt + 15
+    d0 = (kt >> 1) * SKC;
+    const unsigned soff = (unsigned)d0 * 4u;
+    wc4 = bld4(rwc, 16u * (tid & 3), soff);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ra4[i] = bld4(ra, voff[i], soff);
+      rb4[i] = bld4(rb, voff[i], soff);
+    }
+  }
+  template <int PART>
+  __device__ inline void store_part(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) store_part_piece<PART>(lds, i);
+  }
+  template <int PART>
+  __device__ inline void store_part_piece(float* lds, int i) const {
+    const int c = d0 + 4 * (tid & 3);
+    {
+      const int idx = slot(tid, i), rr = row0 + (idx >> 2);
+      const uint32_t e0 = (uint32_t)rr * (uint32_t)g.D + (uint32_t)c;
+      float dummy;
+      float4 o;
+      o.x = gate_dp_t<true, DROP, PART>(g, ra4[i].x, rb4[i].x, wc4.x, dsr[i], e0 + 0, thr, dscale, dummy);
+      o.y = gate_dp_t<true, DROP, PART>(g, ra4[i].y, rb4[i].y, wc4.y, dsr[i], e0 + 1, thr, dscale, dummy);
+      o.z = gate_dp_t<true, DROP, PART>(g, ra4[i].z, rb4[i].z, wc4.z, dsr[i], e0 + 2, thr, dscale, dummy);
+      o.w = gate_dp_t<true, DROP, PART>(g, ra4[i].w, rb4[i].w, wc4.w, dsr[i], e0 + 3, thr, dscale, dummy);
+      split_store4(lds + (idx >> 2) * SROW_F, idx & 3, o);
+    }
+  }
+};
+
+// B[k][n] = rows of Wa / Wb in SplitP_K's k order; the source is k-major, so a thread takes 8 k of one column (SplitM)
+template <int ROWS, int NT>
+struct SplitWab_M {
+  static constexpr int TOTAL = ROWS * 2, NV = (TOTAL + NT - 1) / NT;
+  static_assert(TOTAL % NT == 0, "whole vector slots only");
+  rsrc_t ra, rb;
+  int tid;
+  unsigned hb;
+  unsigned voff[NV];
+  float r[NV][8];
+  __device__ inline void init(const float* wa, const float* wb, int H, int D, int col0, bool) {
+    tid = threadIdx.x; hb = (unsigned)H * 4u;
+    ra = make_rsrc(wa, (unsigned)D * hb);
+    rb = make_rsrc(wb, (unsigned)D * hb);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT, c = col0 + idx % ROWS, kh = idx / ROWS;
+      voff[i] = c < H ? (unsigned)(8 * kh) * hb + (unsigned)c * 4u : OOB;
+    }
+  }
+  __device__ inline void load(int kt) {
+    const bool second = kt & 1;
+    const unsigned soff = (unsigned)((kt >> 1) * SKC) * hb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[i][j] = bld1(second ? rb : ra, voff[i], soff + (unsigned)j * hb);
+  }
+  __device__ inline void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * NT;
+      split_store8(lds + (idx % ROWS) * SROW_F, idx / ROWS, r[i]);
+    }
+  }
+};
+
+// main loop of the split K-dh: dh_mainloop_deep's pair ring (two A copies of one chunk pair each, four B copies) over
+// compute_chunk_split.  nk % 4 == 0; branch-free (the chunk's part is the unrolled position's parity).
+template <class T, class LA, class LB>
+__device__ inline void dh_split_mainloop(const LA& la0, const LB& lb0, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+#pragma unroll
+  for (int mb = 0; mb < T::MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  LA la[2] = {la0, la0};
+  LB lb[4] = {lb0, lb0, lb0, lb0};
+  la[0].load_pair(0); la[1].load_pair(2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lb[j].load(j);
+  la[0].template store_part<0>(lds);
+  lb[0].store(lds + T::A_FLOATS);
+  __syncthreads();
+  constexpr int NS = split_steps<T>();
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int kt = kt0 + j;
+      float* cur = lds + (j & 1) * T::STAGE_FLOATS;
+      float* nxt = lds + ((j + 1) & 1) * T::STAGE_FLOATS;
+      compute_chunk_split<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
+        if (s == 0) {
+          // copy c's pair is fully written once its odd chunk has been stored, i.e. after position 2c of this round
+          if constexpr (j == 1) la[0].load_pair(kt0 + 4);
+          else if constexpr (j == 3) la[1].load_pair(kt0 + 6);
+        }
+        if (s == (NS >= 4 ? 1 : 0)) lb[j].load(kt + 4);
+        // split + LDS writes of chunk kt+1 spread over the steps: A's vector slots first, B last
+        constexpr int PA = LA::NV;
+#pragma unroll
+        for (int q = 0; q < PA; ++q)
+          if (s == q * (NS - 1) / PA) la[((j + 1) & 3) >> 1].template store_part_piece<(j + 1) & 1>(nxt, q);
+        if (s == NS - 1) lb[(j + 1) & 3].store(nxt + T::A_FLOATS);
+      });
+      __syncthreads();
+    });
+  }
+}
+
 template <class T, bool FUSED, int MODE = -1>
 __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   extern __shared__ __align__(16) float lds[];
@@ -260,7 +425,7 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers (FUSED only)
   float* p_l = ds_l + T::BM;
   MMF_KSTAMP(k0);
-  LoadP_K<T::BM, T::NT, MODE> la;
+  std::conditional_t<T::SPLIT, SplitP_K<T::BM, T::NT, (T::SPLIT ? MODE : 2)>, LoadP_K<T::BM, T::NT, MODE>> la;
   if constexpr (FUSED) {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
     // g_i = dM.h_i: every wave takes a contiguous share of the rows; lanes cover float4 pieces of h with 8
@@ -341,13 +506,15 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   } else {
     la.init(p.g, row0, (int)p.N);
   }
-  LoadWab_M<T::BN, T::NT> lb;
+  std::conditional_t<T::SPLIT, SplitWab_M<T::BN, T::NT>, LoadWab_M<T::BN, T::NT>> lb;
   lb.init(p.Wa, p.Wb, p.H, p.g.D, col0, p.g.gated != 0);
   f32x16 acc[T::MB][T::NB];
   f32x4acc acch[T::NB][2];                   // the half block's accumulators (Tile::HALF; unused otherwise)
-  const int nk = (p.g.gated ? 2 : 1) * p.g.D / KC;
+  const int nk = (p.g.gated ? 2 : 1) * p.g.D / (T::SPLIT ? SKC : KC);
   MMF_KSTAMP(k1);
-  if constexpr (T::NT == 256 && T::BM <= 64) {
+  if constexpr (T::SPLIT) {
+    dh_split_mainloop<T>(la, lb, nk, lds, acc);
+  } else if constexpr (T::NT == 256 && T::BM <= 64) {
     if (p.deep && p.g.gated) dh_mainloop_deep<T>(la, lb, nk, lds, acc);       // short grid: see dh_mainloop_deep
     else gemm_mainloop<T, decltype(la), decltype(lb), false>(la, lb, nk, lds, acc);
   } else {
@@ -660,6 +827,126 @@ struct LoadA_M_Gate {
   }
 };
 
+// ---- A operands of the split-operand TN kernel (mmf_gemm_split.h): chunks of 16 instances ---------------------------
+// Plain A[k][m]: SplitM's map (a thread owns ONE column and 8 consecutive instances) + the column sums.
+template <int ROWS, int NT>
+struct SplitA_M_Plain {
+  static constexpr int TOTAL = ROWS * 2;
+  static_assert(TOTAL == NT, "one (column, k half) per thread");
+  rsrc_t rs;
+  unsigned ldb, kbase_b, voff;
+  int tid;
+  bool do_sum;
+  float r[8];
+  float csum;
+  __device__ inline void init(const float* s, int ld, int col0, int ncols, int kbase, int kmax, bool do_sum_) {
+    tid = threadIdx.x; do_sum = do_sum_; csum = 0.f;
+    rs = make_rsrc(s, (unsigned)(kmax > 0 ? kmax : 0) * (unsigned)ld * 4u);
+    ldb = (unsigned)ld * 4u;
+    kbase_b = (unsigned)kbase * ldb;
+    const int c = col0 + tid % ROWS, kh = tid / ROWS;
+    voff = c < ncols ? (unsigned)(8 * kh) * ldb + (unsigned)c * 4u : OOB;
+  }
+  __device__ inline void load(int kt) {
+    const unsigned soff = kbase_b + (unsigned)(kt * SKC) * ldb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = bld1(rs, voff, soff + (unsigned)j * ldb);
+  }
+  __device__ inline void store(float* lds) {
+    split_store8(lds + (tid % ROWS) * SROW_F, tid / ROWS, r);
+    if (do_sum) csum += ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));   // out-of-range reads are 0
+  }
+  static constexpr int PIECES = 1;
+  __device__ inline void store_piece(float* lds, int) { store(lds); }
+  __device__ inline void absorb(const SplitA_M_Plain& o) { csum += o.csum; }     // the copies start from a zero sum
+};
+
+// A[k = instance][m] = dP for DT = ROWS / 2 attention dims d0 .. d0 + DT - 1 (gated: image rows [0, DT) = d pre-tanh,
+// [DT, ROWS) = d pre-sigmoid of the same dims; ungated: DT = ROWS).  A thread owns one dim and 16 DT / NT consecutive
+// instances: it loads a, b, ds once and emits both halves.
+template <int ROWS, int NT, bool GATED, int DROP>
+struct SplitA_M_Gate {
+  static constexpr int DT = GATED ? ROWS / 2 : ROWS;
+  static constexpr int KPT = SKC * DT / NT;            // instances per thread: 4 (gated 256-row tile, 512 threads) or 8
+  static_assert(KPT == 4 || KPT == 8, "plane pieces of 8 or 16 bytes");
+  GateBwdCtx g;
+  rsrc_t ra, rb, rds;
+  int d0, kbase, tid, kt_loaded;
+  bool do_sum;
+  uint32_t thr;
+  float dscale, wc;
+  unsigned db, voff, voff_ds;
+  float ra1[KPT], rb1[KPT], dsr[KPT];
+  float csum_a, csum_b, csum2;   // column sums: d pre-tanh, d pre-sigmoid (bias grads), ds.a_d.b_d (dWc)
+  __device__ inline void init(const GateBwdCtx& g_, int d0_, int kbase_, int kmax, bool do_sum_) {
+    g = g_; g.resolve_seed(); d0 = d0_; kbase = kbase_; tid = threadIdx.x; do_sum = do_sum_;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    csum_a = csum_b = csum2 = 0.f;
+    db = (unsigned)g.D * 4u;
+    const unsigned rows = (unsigned)(kmax > 0 ? kmax : 0);
+    ra = make_rsrc(g.a, rows * db);
+    rb = make_rsrc(GATED ? g.b : g.a, rows * db);
+    rds = make_rsrc(g.ds, rows * 4u);
+    const int c = d0 + tid % DT, kq = tid / DT;
+    const bool ok = c < g.D;
+    wc = bld1(make_rsrc(g.Wc, db), ok ? (unsigned)c * 4u : OOB, 0);
+    voff = ok ? (unsigned)(KPT * kq) * db + (unsigned)c * 4u : OOB;
+    voff_ds = ok ? (unsigned)(KPT * kq) * 4u : OOB;
+    kt_loaded = 0;
+  }
+  __device__ inline void load(int kt) {
+    kt_loaded = kt;
+    const unsigned k0 = (unsigned)(kbase + kt * SKC);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      ra1[j] = bld1(ra, voff, (k0 + j) * db);
+      if (GATED) rb1[j] = bld1(rb, voff, (k0 + j) * db);
+      dsr[j] = bld1(rds, voff_ds, (k0 + j) * 4u);    // 0 beyond the split's last instance => dP = 0 there
+    }
+  }
+  __device__ inline void store(float* lds) {
+    const int dl = tid % DT, kq = tid / DT, c = d0 + dl;
+    GateBwdCtx gg = g;
+    gg.gated = GATED ? 1 : 0;
+    float oa[KPT], ob[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = kbase + kt_loaded * SKC + KPT * kq + j;
+      const uint32_t idx = (uint32_t)k * (uint32_t)g.D + (uint32_t)c;
+      float w;
+      oa[j] = gate_dp_t<GATED, DROP != 0, 0>(gg, ra1[j], GATED ? rb1[j] : 0.f, wc, dsr[j], idx, thr, dscale, w);
+      ob[j] = GATED ? gate_dp_t<GATED, DROP != 0, 1>(gg, ra1[j], rb1[j], wc, dsr[j], idx, thr, dscale, w) : 0.f;
+      if (do_sum) { csum_a += oa[j]; csum_b += ob[j]; csum2 += dsr[j] * w; }
+    }
+    if constexpr (KPT == 4) {
+      split_store4(lds + dl * SROW_F, kq, make_float4(oa[0], oa[1], oa[2], oa[3]));
+      if (GATED) split_store4(lds + (DT + dl) * SROW_F, kq, make_float4(ob[0], ob[1], ob[2], ob[3]));
+    } else {
+      split_store8(lds + dl * SROW_F, kq, oa);
+      if (GATED) split_store8(lds + (DT + dl) * SROW_F, kq, ob);
+    }
+  }
+  static constexpr int PIECES = 1;
+  __device__ inline void store_piece(float* lds, int) { store(lds); }
+  __device__ inline void absorb(const SplitA_M_Gate& o) { csum_a += o.csum_a; csum_b += o.csum_b; csum2 += o.csum2; }
+};
+
+// per-thread scalar column sums: the NT / COLS threads that own column c are tid = c + q COLS
+template <int COLS, int NT>
+__device__ inline void colsum1_reduce_store(float* lds, float v, float* dst, int col0, int ncols) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  lds[tid] = v;
+  __syncthreads();
+  if (tid < COLS) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NT / COLS; ++q) s += lds[q * COLS + tid];
+    if (col0 + tid < ncols) dst[col0 + tid] = s;
+  }
+}
+
 // reduce a per-thread float4 column sum over the NT/(COLS/4) threads that own the same 4 of COLS columns
 template <int COLS, int NT>
 __device__ inline void colsum_reduce_store(float* lds, float4 v, float* dst, int col0, int ncols) {
@@ -718,19 +1005,29 @@ __device__ inline void tn_store(const TnProblem& q, int split, int tn, f32x16 (&
 }
 
 template <class T, bool GATED, int DROP>
-__device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q, LoadM<T::BN, T::NT>& lb, int split, int tm,
+__device__ inline void tn_gate_tile(const TnParams& p, const TnProblem& q,
+                                    std::conditional_t<T::SPLIT, SplitM<T::BN, T::NT>, LoadM<T::BN, T::NT>>& lb, int split, int tm,
                                     int tn, int kbase, int kmax, int nk, int last_groups, bool do_sum, float* lds) {
-  using LA = LoadA_M_Gate<T::BM, T::NT, GATED, DROP>;
+  using LA = std::conditional_t<T::SPLIT, SplitA_M_Gate<T::BM, T::NT, GATED, (DROP > 0 ? 1 : 0)>, LoadA_M_Gate<T::BM, T::NT, GATED, DROP>>;
   constexpr int DT = LA::DT;
   const int D = p.g.D, d0 = tm * DT;
   LA la;
   la.init(p.g, d0, kbase, kmax, do_sum);
   f32x16 acc[T::MB][T::NB];
-  gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
+  if constexpr (T::SPLIT) split_mainloop<T, 2>(la, lb, nk, lds, acc);
+  else gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
   tn_store<T>(q, split, tn, acc, lds, [&](int r) {      // tile row -> row of the stacked [dWa ; dWb] slab
     const int half = r / DT, d = d0 + r - half * DT;
     return d < D ? half * D + d : -1;
   });
+  if constexpr (T::SPLIT) {
+    if (do_sum) {
+      float* cs = q.colsum + (size_t)split * q.colsum_stride;
+      colsum1_reduce_store<DT, T::NT>(lds, la.csum_a, cs, d0, D);
+      if (GATED) colsum1_reduce_store<DT, T::NT>(lds, la.csum_b, cs + D, d0, D);
+      if (q.colsum2) colsum1_reduce_store<DT, T::NT>(lds, la.csum2, q.colsum2 + (size_t)split * q.colsum2_stride, d0, D);
+    }
+  } else
   if (do_sum) {
     float* cs = q.colsum + (size_t)split * q.colsum_stride;
     colsum_reduce_store<DT, T::NT>(lds, la.csum_a, cs, d0, D);
@@ -765,11 +1062,14 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   const int64_t kb64 = (int64_t)split * q.k_per_split;
   const int kbase = (int)(kb64 < p.K ? kb64 : p.K);
   const int kmax = (int)((kb64 + q.k_per_split) < p.K ? (kb64 + q.k_per_split) : p.K);
-  const int nk = (kmax - kbase + KC - 1) / KC;
+  constexpr int CH = T::SPLIT ? SKC : KC;        // instances per staged chunk
+  // split-operand tiles: an even number of chunks (split_mainloop<T, 2>); the padding chunk reads zeros past kmax
+  const int nk = T::SPLIT ? 2 * ((kmax - kbase + 2 * CH - 1) / (2 * CH)) : (kmax - kbase + CH - 1) / CH;
   // fragment groups (2 G instances each) of the last chunk that hold data: splits are cut at multiples of 4 instances,
   // not of whole chunks, so that all of them have the same length (50k bag: 42 x 1192 = 37.25 chunks each, where whole
   // chunks gave 41 x 38 + one split of 4.5)
-  const int last_groups = nk > 0 ? ((kmax - kbase) - (nk - 1) * KC + 2 * T::G - 1) / (2 * T::G) : 0;
+  int last_groups = 0;
+  if constexpr (!T::SPLIT) last_groups = nk > 0 ? ((kmax - kbase) - (nk - 1) * KC + 2 * T::G - 1) / (2 * T::G) : 0;
   const bool do_sum = tn == 0 && q.colsum != nullptr;
 #ifdef MMF_STAMPS             /* workgroup life time by tile kind: [0] sum plain, [1] sum gate, [2] count plain, [3] count gate */
   struct TnLife {
@@ -781,16 +1081,19 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
   } life{stamp_now(), q.kind == TN_A_PLAIN ? 0 : 1};
 #endif
 
-  LoadM<T::BN, T::NT> lb;
+  std::conditional_t<T::SPLIT, SplitM<T::BN, T::NT>, LoadM<T::BN, T::NT>> lb;
   lb.init(q.B, q.ldb, tn * T::BN, q.Ncols, kbase, kmax);
   if (q.kind == TN_A_PLAIN) {
-    LoadA_M_Plain<T::BM, T::NT> la;
+    std::conditional_t<T::SPLIT, SplitA_M_Plain<T::BM, T::NT>, LoadA_M_Plain<T::BM, T::NT>> la;
     la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
     f32x16 acc[T::MB][T::NB];
-    gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
+    if constexpr (T::SPLIT) split_mainloop<T, 2>(la, lb, nk, lds, acc);
+    else gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
     tn_store<T>(q, split, tn, acc, lds, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
-    if (do_sum)
-      colsum_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+    if (do_sum) {
+      if constexpr (T::SPLIT) colsum1_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+      else colsum_reduce_store<T::BM, T::NT>(lds, la.csum, q.colsum + (size_t)split * q.colsum_stride, tm * T::BM, q.M);
+    }
   } else if (p.g.gated) {
     tn_gate_tile<T, true, DROP>(p, q, lb, split, tm, tn, kbase, kmax, nk, last_groups, do_sum, lds);
   } else {
@@ -930,19 +1233,38 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
   return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
 }
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half) {
+bool use_split();
+// the split-operand K-dh: the training step's shape only (gated stack, fused K-prep, wide tiles)
+bool bwd_dh_split_ok(int64_t N, int H, int D, int gated) {
+  return use_split() && gated && use_wide_tiles(N, H) && (2 * D / SKC) % 4 == 0;
+}
+int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
+
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated) {
   static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
   if (dh_short_grid(N, H)) return (int)((N + 63) / 64);
   if (!use_wide_tiles(N, H)) return 0;
+  if (bwd_dh_split_ok(N, H, D, gated)) return (int)((N + bwd_dh_split_rows(N) - 1) / bwd_dh_split_rows(N));
   const int rows = pick_wide_rows(N, H / 256, allow_half != 0);   // the fused launch always has the forward's relu bits
   return (int)((N + rows - 1) / rows);
+}
+
+template <int ROWS>
+static int launch_bwd_dh_split(BwdDhParams p, hipStream_t st) {
+  using T = TileSp<ROWS, 256, 1, 8>;
+  p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  constexpr int extra = (3 * T::BM + 16) * 4;
+  if (p.g.drop_p > 0.f) return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 3>, p, grid, extra, st);
+  return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 2>, p, grid, extra, st);
 }
 
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
+  if (p.fused_prep && bwd_dh_split_ok(p.N, p.H, p.g.D, p.g.gated)) return launch_bwd_dh_split<224>(p, st);
   if (use_wide_tiles(p.N, p.H)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
@@ -1076,6 +1398,7 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
 }
 
 int launch_tn(TnParams p, hipStream_t st) {
+  if (p.tile == 256 && use_split()) return launch_tn_t<TileSp<256, 256, 2, 4>>(p, st);
   if (p.tile == 256) return launch_tn_t<Tile<256, 256, 2, 4, false, false, 2>>(p, st);
   return launch_tn_t<Tile<128, 128, 2, 2, false, false, 2>>(p, st);
 }

@@ -10,6 +10,7 @@
 
 #define MMF_STAMP_FIRST_STAGE      /* stamps builds: this unit owns g_stamps[2..3] for the main loops' first stage */
 #include "mmf_gemm_core.h"
+#include "mmf_gemm_split.h"
 #include "mmf_kernels.h"
 
 namespace mmf {
@@ -156,6 +157,32 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 #endif
 }
 
+// The same projection on the bf16 matrix cores (mmf_gemm_split.h: 3-way operand split, fp32-equivalent accuracy).
+template <class T>
+__global__ __launch_bounds__(T::NT) void linear_nt_split_kernel(LinearParams p) {
+  extern __shared__ __align__(16) float lds[];
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int row0 = mt * T::BM, col0 = nt * T::BN;
+  SplitK<T::BM, T::NT> la;
+  la.init(p.x[0], p.ldx, row0, (int)p.M);
+  SplitK<T::BN, T::NT> lb;
+  lb.init(p.w, p.K, col0, p.N);
+  f32x16 acc[T::MB][T::NB];
+  split_mainloop<T, 4>(la, lb, p.K / SKC, lds, acc);
+  const bool drop = p.drop_p > 0.f;
+  if (p.act == ACT_RELU) {
+    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, nullptr, lds, row0, col0);
+    else linear_epilogue<T, ACT_RELU, false>(p, acc, nullptr, lds, row0, col0);
+  } else if (p.act == ACT_NONE && !drop) {
+    linear_epilogue<T, ACT_NONE, false>(p, acc, nullptr, lds, row0, col0);
+  } else if (drop) {
+    linear_epilogue<T, -1, true>(p, acc, nullptr, lds, row0, col0);
+  } else {
+    linear_epilogue<T, -1, false>(p, acc, nullptr, lds, row0, col0);
+  }
+}
+
 // =============================================================================================
 // K-gate : NT GEMM of h against an interleaved [Wa-block | Wb-block] tile, fused gate epilogue
 // =============================================================================================
@@ -233,13 +260,15 @@ __device__ inline void gate_fwd_tile(const GateFwdParams& p, float* lds, int row
   constexpr int DT = GATED ? T::BN / 2 : T::BN;   // attention dims covered by one tile
   const int d0 = nt * DT;
 
-  LoadK<T::BM, T::NT> la;
+  std::conditional_t<T::SPLIT, SplitK<T::BM, T::NT>, LoadK<T::BM, T::NT>> la;
   la.init(p.h, p.H, row0, (int)p.row_end);
-  LoadGateW<T::BN, T::NT, GATED, false> lb;
+  std::conditional_t<T::SPLIT, SplitGateW<T::BN, T::NT, GATED>, LoadGateW<T::BN, T::NT, GATED, false>> lb;
   lb.init(p.Wa, p.Wb, p.H, p.D, d0);
 
   f32x16 acc[T::MB][T::NB];
-  if constexpr (T::BM <= 64) {
+  if constexpr (T::SPLIT) {
+    split_mainloop<T, 4>(la, lb, p.H / SKC, lds, acc);
+  } else if constexpr (T::BM <= 64) {
     if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, p.H / KC, lds, acc);      // short grid: see gemm_mainloop_deep
     else gemm_mainloop<T>(la, lb, p.H / KC, lds, acc);
   } else {
@@ -702,10 +731,27 @@ static int launch_linear_wide(LinearParams p, hipStream_t st) {
   return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
+bool use_split() {
+  static const int env = getenv("MMF_SPLIT") ? atoi(getenv("MMF_SPLIT")) : 0;
+  return env != 0;
+}
+template <int ROWS, int WM, int WN>
+static int launch_linear_split(LinearParams p, hipStream_t st) {
+  using T = TileSp<ROWS, 256, WM, WN>;
+  p.mt_count = (int)((p.M + T::BM - 1) / T::BM); p.nt_count = p.N / 256;
+  return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+}
+
 int launch_linear(LinearParams p, hipStream_t st) {
   if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
   if (p.M <= 0) return MMF_OK;
+  if (use_split() && use_wide_tiles(p.M, p.N) && p.K % (4 * SKC) == 0 && p.nseg == 1) {
+    static const int rows = getenv("MMF_SPLIT_ROWS") ? atoi(getenv("MMF_SPLIT_ROWS")) : 224;
+    if (rows == 256) return launch_linear_split<256, 2, 4>(p, st);
+    if (rows == 192) return launch_linear_split<192, 1, 8>(p, st);
+    return launch_linear_split<224, 1, 8>(p, st);
+  }
   if (use_wide_tiles(p.M, p.N)) {
     switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0)) {
       case 64: return launch_linear_wide<64>(p, st);
@@ -758,6 +804,9 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   //   D  256 short tiles         -> slot 2's last, so that both slots end at R T
   //   E  the remaining rows as short tiles (twice as many CUs work on them, each for half the time)
   // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
+  using SB = TileSp<128, 128, 2, 2>;
+  using SS = TileSp<64, 128, 2, 2>;
+  const bool split = use_split() && p.H % (4 * SKC) == 0;
   static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
   int64_t mt = (p.N + 127) / 128;
   const int64_t slots = 512, total = mt * p.nt_count;
@@ -784,11 +833,17 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
     }
     region(0, (p.N - row + 63) / 64);
     p.nreg = n;
+    if (split)
+      return p.gated ? launch_tiled<SB>("gate_fwd_split_kernel", gate_fwd_mixed_kernel<SB, SS, true>, p, grid, st)
+                     : launch_tiled<SB>("gate_fwd_split_kernel", gate_fwd_mixed_kernel<SB, SS, false>, p, grid, st);
     return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, true>, p, grid, st)
                    : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_mixed_kernel<TileNT128, TS, false>, p, grid, st);
   }
   p.mt_count = (int)mt;
   const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  if (split)
+    return p.gated ? launch_tiled<SB>("gate_fwd_split_kernel", gate_fwd_kernel<SB, true>, p, grid, st)
+                   : launch_tiled<SB>("gate_fwd_split_kernel", gate_fwd_kernel<SB, false>, p, grid, st);
   return p.gated ? launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, true>, p, grid, st)
                  : launch_tiled<TileNT128>("gate_fwd_kernel", gate_fwd_kernel<TileNT128, false>, p, grid, st);
 }

@@ -346,7 +346,7 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
-  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1);
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1, d->D, d->gated);
   if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
     dp.fused_prep = 1;
     dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;

@@ -42,6 +42,7 @@ template <int BM_, int BN_, int WM_, int WN_, bool A_KCONTIG_, bool B_KCONTIG_, 
 struct Tile {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, G = G_;
   static constexpr bool BF16 = BF16_;
+  static constexpr bool SPLIT = false;     // true: TileSp (mmf_gemm_split.h)
   static_assert(G_ == 4 || (G_ == 2 && !A_KCONTIG_ && !B_KCONTIG_), "G = 2 only for all-m-contiguous tiles");
   static_assert(!BF16_ || (A_KCONTIG_ && B_KCONTIG_ && G_ == 4), "bf16 tiles are k-contiguous on both sides");
   static constexpr bool A_KCONTIG = A_KCONTIG_, B_KCONTIG = B_KCONTIG_;

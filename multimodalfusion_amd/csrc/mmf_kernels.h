@@ -222,7 +222,7 @@ int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A
 int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
 int pick_wide_rows(int64_t M, int ntn, bool allow_half);

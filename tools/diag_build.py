@@ -11,6 +11,8 @@ nogload: the fp32 main loops write stale registers to LDS and issue no global lo
 epi1: row-major epilogues write only their first row block
 nobar / nosched: nofrag + no barrier between chunks / + no sched_barrier around the MFMA blocks
 nostore / noepi: the projection kernel's epilogue without its global stores / no epilogue at all
+s_*: the same for the split-operand core (mmf_gemm_split.h): no MFMA / no staging at all / no global loads / LDS writes of
+     unsplit data / no staging and no barrier
 """
 import os
 import subprocess
@@ -27,6 +29,8 @@ VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "nofrag": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG"],
             "epi1": ["-DMMF_DIAG_EPI1"], "nogload": ["-DMMF_DIAG_NOGLOAD"],
             "nobar": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR"],
+            "s_nomfma": ["-DMMF_SDIAG_NOMFMA"], "s_nostage": ["-DMMF_SDIAG_NOSTAGE"], "s_nogload": ["-DMMF_SDIAG_NOGLOAD"],
+            "s_nosplit": ["-DMMF_SDIAG_NOSPLIT"], "s_freesched": ["-DMMF_SPLIT_FREE_SCHED"], "s_nobar": ["-DMMF_SDIAG_NOSTAGE", "-DMMF_SDIAG_NOBAR"],
             "nosched": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR", "-DMMF_DIAG_NOSCHED"]}
 
 
