@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the bag and saved activations; f32 is the BASELINE metric, bf16 is config 5 "
                          "(bf16 MFMA, fp32 accumulate/epilogues; HBM roofline)")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="f32",
+                    help="f32 bags only (mmf_amil_desc::gemm): f32 = exact-fp32 MFMA (the BASELINE metric's arithmetic, default); "
+                         "bf16x3 = every fp32 operand as the sum of three bf16 values on the bf16 matrix cores, fp32 accumulation "
+                         "(fp32-equivalent error: tests/test_gpu_split.py).  The default run reports it as the extra leg `gemm_bf16x3`")
     return ap.parse_args()
 
 
@@ -237,6 +241,8 @@ def kernel_tables(N, L=1024, H=256, D=256):
         "bwd_dh_kernel": 2 * 2 * H * D * N,
         "tn_kernel": (2 * H * L + 2 * 2 * D * H) * N,
     }
+    for k in ("linear_nt", "gate_fwd", "bwd_dh", "tn"):       # the same contractions on the split-operand core
+        kflops[k + "_split_kernel"] = kflops[k + "_kernel"]
     kbytes = {
         "amil_fwd_fused_bf16_kernel": N * (L * 2 + H * 2 + 2 * D * 2 + 4),     # x read; h, a, b, A_raw written
         "linear_bf16_kernel": N * (L * 2 + H * 2),                             # x read, h written
@@ -261,6 +267,14 @@ def roofline_of(prof, N, bf16):
         return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source, "avg_launch_us": t_us,
                 "bytes_per_launch": kbytes[dom]}
+    if dom.endswith("_split_kernel"):
+        # six bf16 MFMAs carry one fp32 product's worth of k: the roofline is the dense bf16 peak / 6, in fp32 FLOP
+        ach = kflops[dom] / (t_us * 1e-6) / 1e12
+        peak = BF16_MFMA_PEAK_TFLOPS / 6
+        return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "peak_note": "dense bf16 MFMA peak / 6 products per fp32 product (bf16x3 split operands)",
+                "x_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
+                "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
     if dom in kflops:
         ach = kflops[dom] / (t_us * 1e-6) / 1e12
         return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -322,6 +336,33 @@ def graph_leg(model, dev, steps, gen):
     for p in model.parameters():
         p.grad = None
     return res
+
+
+def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
+    """The default workload with mmf_amil_desc::gemm = MMF_GEMM_BF16X3: same bag, same model, same step; reported beside
+    `value`, never as `value` (the BASELINE metric is quoted on exact-fp32 arithmetic)."""
+    import torch
+    from multimodalfusion_amd import ops
+    N = x.shape[0]
+    prev = ops.set_gemm(1)
+    try:
+        one = make_step(model, x, dev, None, 1)
+        d1 = time_steps(one, steps, warmup, 1)
+        prof = kernel_profile(one, max(5, min(steps, 20)))
+        dn = time_steps(make_step_inflight(model, x, dev, 1, inflight), steps, warmup, 1)
+    finally:
+        ops.set_gemm(prev)
+        for p in model.parameters():
+            p.grad = None
+    ms1 = 1e3 * d1 / steps
+    return {"arithmetic": "fp32 operands split into three bf16 values each, six v_mfma_f32_32x32x16_bf16 products per fp32 "
+                          "product, fp32 accumulation; inputs, outputs, saved activations and gradients fp32",
+            "accuracy": "error against the fp64 oracle within 2x the exact-fp32 path's, output by output: tests/test_gpu_split.py",
+            "value_one_bag_per_step": steps / d1, "ms_per_step_one_bag": ms1,
+            "value": steps / dn, "bags_in_flight": inflight,
+            "whole_step_x_fp32_mfma_peak": flops_per_bag(N) / (ms1 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": roofline_of(prof, N, False),
+            "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}}
 
 
 def config5_leg(dev, steps, warmup, gen):
@@ -538,6 +579,9 @@ def main():
     if bf16:
         x = x.to(torch.bfloat16)
     inflight = args.inflight if args.inflight > 0 else (2 if bf16 else 3)
+    if args.gemm == "bf16x3" and not bf16:
+        from multimodalfusion_amd import ops
+        ops.set_gemm(1)
     ag = args.autograd
     step = (make_step(model, x, dev, flat, world, ag) if inflight == 1
             else make_step_inflight(model, x, dev, world, inflight, ag))
@@ -550,7 +594,7 @@ def main():
         "metric": "bags/sec fwd+bwd, path-AMIL 50k x 1024 synthetic bag" if N == 50000 else f"bags/sec fwd+bwd, path-AMIL {N} x 1024 synthetic bag",
         "value": value, "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype if args.gemm == "f32" or bf16 else "f32 (bf16x3 split operands on the bf16 MFMA, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) {'bf16 ' if bf16 else ''}bag per GPU per step, "
                                f"nll_surv alpha=0, {'eval' if args.eval_mode else 'train (1 dropout mask)'} mode, "
                                f"fwd+loss+bwd, grads materialised, "
@@ -604,6 +648,8 @@ def main():
                                   "autograd_surface_ms_per_step": 1e3 * d3 / args.steps}
             out["other_sizes"] = extra
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
+            if not bf16 and args.gemm == "f32":
+                out["gemm_bf16x3"] = gemm_bf16x3_leg(model, x, dev, args.steps, args.warmup, inflight)
             if not bf16 and N == 50000:
                 out["config5_bf16_100k"] = config5_leg(dev, max(10, args.steps), args.warmup, g)
                 out["other_configs"] = other_configs_leg(dev, max(10, min(args.steps, 30)), args.warmup, g)

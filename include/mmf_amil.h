@@ -72,7 +72,19 @@ typedef struct mmf_amil_desc {
                               * beside it on other streams (pipeline.BagsInFlight) -- 224-row tiles, which leave 32 CUs
                               * to the neighbours, gave the higher aggregate rate in two of three same-run comparisons
                               * (1376 vs 1337 bags/s with three bags in flight) and the same rate in the third. */
+  int32_t gemm;              /* how the stack's four large fp32 contractions are multiplied (fp32 calls only; inputs,
+                              * outputs, saved activations and accumulation are fp32 either way):
+                              *   MMF_GEMM_F32    (0) v_mfma_f32_32x32x2_f32, the exact-fp32 matrix instruction;
+                              *   MMF_GEMM_BF16X3 (1) every fp32 operand as the exact sum of three bf16 values, the six
+                              *                       leading products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+                              *                       (csrc/mmf_gemm_split.h).  Same error against an fp64 product as
+                              *                       mode 0 (tests/test_gpu_split.py), 2.67 x its instruction rate.
+                              *                       Taken for gated stacks on bags large enough for the wide tiles
+                              *                       (N >= 16384 at H = 256); other shapes run mode 0.  Operands
+                              *                       within one bf16 ulp of FLT_MAX, or infinite, give NaN. */
 } mmf_amil_desc;
+#define MMF_GEMM_F32 0
+#define MMF_GEMM_BF16X3 1
 
 typedef struct mmf_amil_grads {
   float* dW1; float* db1;

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -24,7 +24,7 @@ class AmilDesc(C.Structure):
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("Wa", C.c_void_p), ("ba", C.c_void_p),
         ("Wb", C.c_void_p), ("bb", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
         ("p_h", C.c_float), ("p_att", C.c_float), ("seed", C.c_uint32),
-        ("seed_dev", C.c_void_p), ("trace", C.c_void_p), ("concurrent", C.c_int32),
+        ("seed_dev", C.c_void_p), ("trace", C.c_void_p), ("concurrent", C.c_int32), ("gemm", C.c_int32),
     ]
 
 

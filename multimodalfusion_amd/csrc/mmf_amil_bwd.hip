@@ -1233,20 +1233,19 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
   return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
 }
-bool use_split();
 // the split-operand K-dh: the training step's shape only (gated stack, fused K-prep, wide tiles)
-bool bwd_dh_split_ok(int64_t N, int H, int D, int gated) {
-  return use_split() && gated && use_wide_tiles(N, H) && (2 * D / SKC) % 4 == 0;
+bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {
+  return split && gated && use_wide_tiles(N, H) && (2 * D / SKC) % 4 == 0;
 }
 int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
 
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated) {
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split) {
   static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
   if (dh_short_grid(N, H)) return (int)((N + 63) / 64);
   if (!use_wide_tiles(N, H)) return 0;
-  if (bwd_dh_split_ok(N, H, D, gated)) return (int)((N + bwd_dh_split_rows(N) - 1) / bwd_dh_split_rows(N));
+  if (bwd_dh_split_ok(N, H, D, gated, split)) return (int)((N + bwd_dh_split_rows(N) - 1) / bwd_dh_split_rows(N));
   const int rows = pick_wide_rows(N, H / 256, allow_half != 0);   // the fused launch always has the forward's relu bits
   return (int)((N + rows - 1) / rows);
 }
@@ -1264,7 +1263,7 @@ static int launch_bwd_dh_split(BwdDhParams p, hipStream_t st) {
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
-  if (p.fused_prep && bwd_dh_split_ok(p.N, p.H, p.g.D, p.g.gated)) return launch_bwd_dh_split<224>(p, st);
+  if (p.fused_prep && bwd_dh_split_ok(p.N, p.H, p.g.D, p.g.gated, p.split)) return launch_bwd_dh_split<224>(p, st);
   if (use_wide_tiles(p.N, p.H)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
@@ -1329,8 +1328,9 @@ int tn_splits(int64_t K, int total_tiles, int tile) {
 template <class T>
 static int launch_tn_grid(const TnParams& p, int grid, hipStream_t st) {
   if constexpr (T::BM == 256) {
-    if (p.g.drop_p > 0.f) return launch_tiled<T>("tn_kernel", tn_kernel<T, 1>, p, grid, st);
-    return launch_tiled<T>("tn_kernel", tn_kernel<T, 0>, p, grid, st);
+    const char* name = T::SPLIT ? "tn_split_kernel" : "tn_kernel";
+    if (p.g.drop_p > 0.f) return launch_tiled<T>(name, tn_kernel<T, 1>, p, grid, st);
+    return launch_tiled<T>(name, tn_kernel<T, 0>, p, grid, st);
   }
   return launch_tiled<T>("tn_kernel", tn_kernel<T>, p, grid, st);
 }
@@ -1398,7 +1398,7 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
 }
 
 int launch_tn(TnParams p, hipStream_t st) {
-  if (p.tile == 256 && use_split()) return launch_tn_t<TileSp<256, 256, 2, 4>>(p, st);
+  if (p.tile == 256 && p.split) return launch_tn_t<TileSp<256, 256, 2, 4>>(p, st);
   if (p.tile == 256) return launch_tn_t<Tile<256, 256, 2, 4, false, false, 2>>(p, st);
   return launch_tn_t<Tile<128, 128, 2, 2, false, false, 2>>(p, st);
 }

@@ -731,10 +731,6 @@ static int launch_linear_wide(LinearParams p, hipStream_t st) {
   return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
-bool use_split() {
-  static const int env = getenv("MMF_SPLIT") ? atoi(getenv("MMF_SPLIT")) : 0;
-  return env != 0;
-}
 template <int ROWS, int WM, int WN>
 static int launch_linear_split(LinearParams p, hipStream_t st) {
   using T = TileSp<ROWS, 256, WM, WN>;
@@ -746,7 +742,7 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
   if (p.M <= 0) return MMF_OK;
-  if (use_split() && use_wide_tiles(p.M, p.N) && p.K % (4 * SKC) == 0 && p.nseg == 1) {
+  if (p.split && use_wide_tiles(p.M, p.N) && p.K % (4 * SKC) == 0 && p.nseg == 1) {
     static const int rows = getenv("MMF_SPLIT_ROWS") ? atoi(getenv("MMF_SPLIT_ROWS")) : 224;
     if (rows == 256) return launch_linear_split<256, 2, 4>(p, st);
     if (rows == 192) return launch_linear_split<192, 1, 8>(p, st);
@@ -806,7 +802,7 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
   using SB = TileSp<128, 128, 2, 2>;
   using SS = TileSp<64, 128, 2, 2>;
-  const bool split = use_split() && p.H % (4 * SKC) == 0;
+  const bool split = p.split && p.H % (4 * SKC) == 0;
   static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
   int64_t mt = (p.N + 127) / 128;
   const int64_t slots = 512, total = mt * p.nt_count;

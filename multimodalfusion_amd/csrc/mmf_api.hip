@@ -248,7 +248,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 8; }
+int mmf_abi_version(void) { return 9; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -287,6 +287,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   lp.relu_bits = infer ? nullptr : w.relu_bits;
   lp.allow_half = d->concurrent ? 0 : 1;
+  lp.split = d->gemm == MMF_GEMM_BF16X3;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
@@ -294,6 +295,7 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   gp.a = w.a; gp.b = w.b; gp.s_part = w.s_part;
   gp.N = d->N; gp.H = d->H; gp.D = d->D; gp.gated = d->gated;
   gp.drop_p = d->p_att; gp.key_a = drop_key(d->seed, 1); gp.key_b = drop_key(d->seed, 2); gp.seed_dev = seed_dev;
+  gp.split = d->gemm == MMF_GEMM_BF16X3;
   if (int e = launch_gate_fwd(gp, st)) return e;
 
   PoolParams pp{};
@@ -343,10 +345,11 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.relu_bits = w.relu_bits;
   dp.allow_half = d->concurrent ? 0 : 1;
+  dp.split = d->gemm == MMF_GEMM_BF16X3;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
-  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1, d->D, d->gated);
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1, d->D, d->gated, dp.split);
   if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
     dp.fused_prep = 1;
     dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
@@ -370,6 +373,7 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
 
   TnParams tp{};
   tp.nprob = 2; tp.K = d->N; tp.splits = w.splits; tp.k_per_split = w.k_per_split; tp.g = gc; tp.tile = w.tile;
+  tp.split = dp.split;
   TnProblem& q1 = tp.prob[0];   // dW1[H x L] = du^T . x ; db1 = colsum(du)
   q1.kind = TN_A_PLAIN; q1.A = w.du; q1.lda = d->H; q1.M = d->H;
   q1.B = x; q1.ldb = d->L; q1.Ncols = d->L;

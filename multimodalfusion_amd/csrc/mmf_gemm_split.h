@@ -258,6 +258,7 @@ __device__ inline void compute_chunk_split(const float* __restrict__ As, const f
       for (int m = 0; m < GM; ++m)
         if ((s + 1) * GM + m < T::MB) read_frag(a0 + ((s + 1) * GM + m) * 32 * SROW_F, fa[(s + 1) & 1][m]);
     }
+    __builtin_amdgcn_sched_barrier(0);       // the reads stay up here (left free, hipcc sank them to the end of the step)
     // The step's staging work (hook) and its MFMAs are ONE scheduling region: the split's VALU work has no
     // dependence on the MFMAs and hipcc interleaves the two streams (a few VALU instructions behind every MFMA).
     // Fenced off from each other, both waves of a SIMD did their MFMAs and then their staging, in phase, and the

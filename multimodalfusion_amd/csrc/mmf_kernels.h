@@ -31,6 +31,7 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   unsigned long long* relu_bits;
   int allow_half;          // 1: the 208-row half-block tile may be chosen (the stack's projection with mmf_amil_desc::concurrent == 0)
   int deep;                // set by launch_linear: short grid, use the deep-prefetch main loop
+  int split;               // 1: the split-operand core (mmf_gemm_split.h) where the shape has a tile for it
 };
 
 struct GateFwdParams {
@@ -50,6 +51,7 @@ struct GateFwdParams {
   struct Region { int64_t row0; int mt_count, grid_begin, tall; } reg[5];
   int nreg;
   int deep;                     // set by launch_gate_fwd: short grid, use the deep-prefetch main loop
+  int split;                    // 1: the split-operand core (mmf_gemm_split.h) where the shape has a tile for it
 };
 
 // Optional tail behind K-merge, ONE single-workgroup launch (head_tail_kernel; for small bags it does the merge too):
@@ -165,6 +167,7 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   int mt_count, nt_count;
   int deep;                // set by launch_bwd_dh: short grid, deep-prefetch main loop (dh_mainloop_deep)
   int allow_half;          // 1: the 208-row half-block tile may be chosen (needs fused_prep, relu_bits, concurrent == 0)
+  int split;               // 1: the split-operand core (mmf_gemm_split.h): gated stacks with fused K-prep on wide tiles
   // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
   // in LDS for its loader / epilogue and publishes them for the TN kernel
   int fused_prep;
@@ -194,6 +197,7 @@ struct TnParams {
   int total_tiles;         // tiles over all problems (set by launch_tn)
   int xcd_map;             // 0: plain order (problem, split, tile); 2: block -> (split, tile) through `map`
   int tile;                // 128 or 256 (set by the caller from tn_tile_dim)
+  int split;               // 1: split-operand 256 x 256 tiles (mmf_gemm_split.h) when tile == 256
   GateBwdCtx g;
   // xcd_map == 2: map[b] = split << 5 | tile (0xFFFF: no work).  Blocks b, b+8, b+16, ... run on the same XCD, and
   // launch_tn() packs the tiles of one (split, problem) -- which read the same A or B panel -- next to each other
@@ -222,7 +226,7 @@ int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A
 int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
 int pick_wide_rows(int64_t M, int ntn, bool allow_half);

@@ -6,6 +6,7 @@ step of the path runs in the HIP kernels of libmmf_amil.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -21,9 +22,19 @@ _drop_calls = 0
 #               hipGraph); each autograd node remembers the word its forward used, so its backward uses the same one;
 #   _trace      an mmf_trace handle (bench.py's roofline leg: per-kernel HIP-event timing on the launch stream).
 #   _concurrent scheduling hint (mmf_amil_desc::concurrent): pipeline.BagsInFlight raises it while it issues a bag.
+#   _gemm       mmf_amil_desc::gemm: 0 = exact-fp32 MFMA, 1 = split-operand bf16x3 (fp32-equivalent error, faster on large
+#               bags); starts from the MMF_GEMM environment variable (0 / 1, default 0).
 _seed_word = None
 _trace = None
 _concurrent = 0
+_gemm = int(os.environ.get("MMF_GEMM", "0"))
+
+
+def set_gemm(mode):
+    """mode: 0 (exact fp32 MFMA) or 1 (bf16x3 split operands).  Returns the previous one."""
+    global _gemm
+    prev, _gemm = _gemm, int(mode)
+    return prev
 
 
 def set_concurrent(flag):
@@ -50,7 +61,7 @@ def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, se
                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF,
-                    seed_dev=ptr(seed_word), trace=_trace, concurrent=_concurrent)
+                    seed_dev=ptr(seed_word), trace=_trace, concurrent=_concurrent, gemm=_gemm)
 
 
 def next_dropout_seed() -> int:

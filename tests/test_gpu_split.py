@@ -1,0 +1,91 @@
+"""GPU parity of mmf_amil_desc::gemm = MMF_GEMM_BF16X3 (csrc/mmf_gemm_split.h): the stack's four large contractions on
+the bf16 matrix cores with every fp32 operand split into three bf16 values (six products, fp32 accumulation).
+
+Two bars:
+  * the same bars as the exact-fp32 path (tests/test_gpu_path.py) against the live fp64 oracle, on bags that take the
+    split tiles (wide row tiles, 256x256 split-K tile), ragged, with and without the dropout sites;
+  * the claim the mode rests on -- fp32-equivalent accuracy: its error against the fp64 oracle is compared with the
+    exact-fp32 path's error on the same inputs, output by output (it must not exceed 2 x that error + rounding noise).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from test_gpu_path import compare, relu_kink_units, run_path_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def split_mode():
+    from multimodalfusion_amd import ops
+    prev = ops.set_gemm(1)
+    yield
+    ops.set_gemm(prev)
+
+
+def _case(N, gated=True, dropout=False, train=True, size="small"):
+    return dict(N=N, gated=gated, size=size, K=4, dropout=dropout, y=N % 4, c=N % 2, alpha=0.1, bias_std=0.05,
+                train=train, seed=4200 + N, x_seed=5200 + N, mask_seed=4321)
+
+
+@pytest.mark.parametrize("N,dropout,train,size", [
+    (16421, False, True, "small"),     # smallest bags on the split tiles, ragged last tile, one dropout site
+    (23333, True, True, "small"),      # + attention dropout: the (gated, dropout) instantiations of K-dh and K-tn
+    (20011, False, False, "small"),    # eval mode
+    (17011, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile in K-dh, three gate tiles in K-tn
+])
+def test_split_against_fp64_oracle(N, dropout, train, size, split_mode, monkeypatch):
+    m = _case(N, dropout=dropout, train=train, size=size)
+    sd, x, _ = cases.path_inputs(m)
+    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"bf16x3 N={N} dropout={dropout} train={train} {size}",
+            kink_units=relu_kink_units(sd, x))
+
+
+def test_split_kernels_are_the_ones_that_ran(split_mode, monkeypatch):
+    """The mode must not silently fall back: the kernel trace of a step on a large gated bag names the split kernels."""
+    from multimodalfusion_amd._lib import KernelTrace
+    m = _case(16421)
+    with KernelTrace() as tr:
+        run_path_hip(m, monkeypatch)
+    names = set(tr.dump().keys())
+    assert {"linear_nt_split_kernel", "gate_fwd_split_kernel", "bwd_dh_split_kernel", "tn_split_kernel"} <= names, names
+    assert not {"linear_nt_kernel", "gate_fwd_kernel", "bwd_dh_kernel", "tn_kernel"} & names, names
+
+
+def test_split_error_matches_exact_fp32(monkeypatch):
+    """fp32-equivalent accuracy, measured: per output, |bf16x3 - fp64| <= 2 |fp32 MFMA - fp64| + a rounding floor."""
+    from multimodalfusion_amd import ops
+    m = _case(32768 + 77, dropout=True)
+    ref = cases.run_path(m)
+    sd, x, _ = cases.path_inputs(m)
+    kink = relu_kink_units(sd, x)
+    res = {}
+    for mode in (0, 1):
+        prev = ops.set_gemm(mode)
+        try:
+            res[mode] = run_path_hip(m, monkeypatch)
+        finally:
+            ops.set_gemm(prev)
+
+    def err(r, key):
+        return float(np.abs(np.asarray(r[key], np.float64) - np.asarray(ref[key], np.float64)).max())
+
+    report = {}
+    for key in ("A_raw", "hazards", "S"):
+        e0, e1 = err(res[0], key), err(res[1], key)
+        report[key] = (e0, e1)
+        assert e1 <= 2 * e0 + 2e-7 * max(1.0, float(np.abs(ref[key]).max())), (key, e0, e1)
+    for k, g in ref["grads"].items():
+        g = np.asarray(g, np.float64)
+        d0 = np.abs(res[0]["grads"][k] - g)
+        d1 = np.abs(res[1]["grads"][k] - g)
+        if k in ("attention_net_WSI.0.weight", "attention_net_WSI.0.bias"):   # rows on the ReLU kink differ legitimately (see compare)
+            keep = np.ones(g.shape[0], bool)
+            keep[list(kink)] = False
+            d0, d1 = d0[keep], d1[keep]
+        e0, e1 = float(d0.max()), float(d1.max())
+        report[k] = (e0, e1)
+        assert e1 <= 2 * e0 + 2e-7 * max(float(np.abs(g).max()), 1e-30), (k, e0, e1)
+    print("max abs error vs fp64 (exact fp32, bf16x3):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})

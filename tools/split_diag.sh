@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase split of the split-operand kernels: kernel averages of the 50k step under the s_* diagnostic builds
-export MMF_SPLIT=1
+export MMF_GEMM=1
 for v in ${VARIANTS:-normal s_freesched s_nomfma s_nostage s_nosplit s_nobar noepi}; do
   if [ "$v" = normal ]; then unset MMF_LIB_PATH; else export MMF_LIB_PATH=$PWD/multimodalfusion_amd/_diag/libmmf_$v.so; fi
   echo "== $v"

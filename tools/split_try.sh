@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of the split-operand (bf16x3) GEMM path: parity tests with MMF_SPLIT=1, then kernel stats of the 50k step.
+# A/B of the split-operand (bf16x3) GEMM path: parity tests with MMF_GEMM=1, then kernel stats of the 50k step.
 R=$GRAFT_REPO_ROOT
-export MMF_SPLIT=1
+export MMF_GEMM=1
 cd $R && timeout -k 10 600 python -m pytest tests/test_gpu_path.py tests/test_gpu_nll_step.py -x -q -m gpu > $R/gpurun_out/split_tests.log 2>&1 || { tail -30 $R/gpurun_out/split_tests.log; exit 1; }
 tail -3 $R/gpurun_out/split_tests.log
 cd /tmp && export TMPDIR=/tmp
