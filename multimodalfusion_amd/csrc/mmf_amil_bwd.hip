@@ -848,6 +848,9 @@ struct SplitA_M_Plain {
     voff = c < ncols ? (unsigned)(8 * kh) * ldb + (unsigned)c * 4u : OOB;
   }
   __device__ inline void load(int kt) {
+#ifdef MMF_SDIAG_NOGLOAD
+    if (kt >= 4) return;
+#endif
     const unsigned soff = kbase_b + (unsigned)(kt * SKC) * ldb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = bld1(rs, voff, soff + (unsigned)j * ldb);

@@ -52,10 +52,15 @@ __device__ inline void split_pair(float x0, float x1, uint32_t& p0, uint32_t& p1
   r0 -= __uint_as_float(p1 << 16); r1 -= __uint_as_float(p1 & 0xFFFF0000u);
   p2 = cvt_pk_bf16(r0, r1);
 }
+#ifdef MMF_SDIAG_NOLDSW        /* diagnostic build: the split is computed, nothing is written to LDS (results are wrong) */
+__device__ inline void st_u2(float* p, uint32_t a, uint32_t b) { asm volatile("" :: "v"(a), "v"(b), "v"(p)); }
+__device__ inline void st_u4(float* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(p)); }
+#else
 __device__ inline void st_u2(float* p, uint32_t a, uint32_t b) { *reinterpret_cast<uint2*>(p) = make_uint2(a, b); }
 __device__ inline void st_u4(float* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 }
+#endif
 // 4 consecutive k of one row -> the row's three planes (8 bytes each) at k offset 4 c4
 __device__ inline void split_store4(float* row, int c4, const float4& v) {
   uint32_t a0, a1, a2, b0, b1, b2;
@@ -200,6 +205,9 @@ struct SplitM {
     }
   }
   __device__ inline void load(int kt) {
+#ifdef MMF_SDIAG_NOGLOAD
+    if (kt >= 4) return;
+#endif
     const unsigned soff = kbase_b + (unsigned)(kt * SKC) * ldb;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
