@@ -279,7 +279,7 @@ struct SplitP_K {
     rwc = make_rsrc(g.Wc, (unsigned)g.D * 4u);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = slot(tid, i), rr = row0 + (idx >> 2);
+      const int idx = slot(tid, i), rr = row0 + krow(idx);
       voff[i] = rr < nrows ? ((unsigned)rr * (unsigned)g.D + 4u * (idx & 3)) * 4u : OOB;
     }
   }
@@ -288,7 +288,7 @@ struct SplitP_K {
     rsrc_t rds = make_rsrc(g.ds, (unsigned)nrows * 4u);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int rr = row0 + (slot(tid, i) >> 2);
+      const int rr = row0 + (krow(slot(tid, i)));
       dsr[i] = bld1(rds, rr < nrows ? (unsigned)rr * 4u : OOB, 0);     // rows beyond the bag: ds = 0 => dP = 0
     }
   }
@@ -296,7 +296,7 @@ struct SplitP_K {
     init_common(g_, row0_, nrows);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int rl = slot(tid, i) >> 2;
+      const int rl = krow(slot(tid, i));
       dsr[i] = row0 + rl < nrows ? ds_lds[rl] : 0.f;
     }
   }
@@ -319,7 +319,7 @@ struct SplitP_K {
   __device__ inline void store_part_piece(float* lds, int i) const {
     const int c = d0 + 4 * (tid & 3);
     {
-      const int idx = slot(tid, i), rr = row0 + (idx >> 2);
+      const int idx = slot(tid, i), rr = row0 + krow(idx);
       const uint32_t e0 = (uint32_t)rr * (uint32_t)g.D + (uint32_t)c;
       float dummy;
       float4 o;
@@ -327,15 +327,86 @@ struct SplitP_K {
       o.y = gate_dp_t<true, DROP, PART>(g, ra4[i].y, rb4[i].y, wc4.y, dsr[i], e0 + 1, thr, dscale, dummy);
       o.z = gate_dp_t<true, DROP, PART>(g, ra4[i].z, rb4[i].z, wc4.z, dsr[i], e0 + 2, thr, dscale, dummy);
       o.w = gate_dp_t<true, DROP, PART>(g, ra4[i].w, rb4[i].w, wc4.w, dsr[i], e0 + 3, thr, dscale, dummy);
-      split_store4(lds + (idx >> 2) * SROW_F, idx & 3, o);
+      split_store4(lds + krow(idx) * SROW_F, idx & 3, o);
     }
   }
 };
 
+// Ungated stacks (MODE = 0 | dropout): one part, chunk kt = attention dims 16 kt .. 16 kt + 15; a plain split_mainloop
+// loader (load / store_piece).
+template <int ROWS, int NT, int MODE>
+struct SplitP_U {
+  static_assert(MODE == 0 || MODE == 1, "ungated, switches compiled in");
+  static constexpr bool DROP = (MODE & 1) != 0;
+  static constexpr int TOTAL = ROWS * 4, NV = (TOTAL + NT - 1) / NT, PIECES = NV;
+  static_assert(TOTAL >= NT, "tile too small for this thread count");
+  GateBwdCtx g;
+  rsrc_t ra, rwc;
+  int row0, tid, d0;
+  uint32_t thr;
+  float dscale;
+  unsigned voff[NV];
+  float dsr[NV];
+  float4 ra4[NV], wc4;
+  __device__ static inline int slot(int tid, int i) { const int idx = tid + i * NT; return idx < TOTAL ? idx : idx - NT; }
+  __device__ inline void init_common(const GateBwdCtx& g_, int row0_, int nrows) {
+    g = g_; g.resolve_seed(); row0 = row0_; tid = threadIdx.x;
+    thr = drop_threshold(g.drop_p);
+    dscale = g.drop_p > 0.f ? 1.0f / (1.0f - g.drop_p) : 1.0f;
+    ra = make_rsrc(g.a, (unsigned)nrows * (unsigned)g.D * 4u);
+    rwc = make_rsrc(g.Wc, (unsigned)g.D * 4u);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = slot(tid, i), rr = row0 + krow(idx);
+      voff[i] = rr < nrows ? ((unsigned)rr * (unsigned)g.D + 4u * (idx & 3)) * 4u : OOB;
+    }
+  }
+  __device__ inline void init(const GateBwdCtx& g_, int row0_, int nrows) {
+    init_common(g_, row0_, nrows);
+    rsrc_t rds = make_rsrc(g.ds, (unsigned)nrows * 4u);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int rr = row0 + krow(slot(tid, i));
+      dsr[i] = bld1(rds, rr < nrows ? (unsigned)rr * 4u : OOB, 0);
+    }
+  }
+  __device__ inline void init_lds(const GateBwdCtx& g_, int row0_, int nrows, const float* ds_lds) {
+    init_common(g_, row0_, nrows);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int rl = krow(slot(tid, i));
+      dsr[i] = row0 + rl < nrows ? ds_lds[rl] : 0.f;
+    }
+  }
+  __device__ inline void load(int kt) {
+    d0 = kt * SKC;
+    const unsigned soff = (unsigned)d0 * 4u;
+    wc4 = bld4(rwc, 16u * (tid & 3), soff);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ra4[i] = bld4(ra, voff[i], soff);
+  }
+  __device__ inline void store_piece(float* lds, int i) const {
+    const int c = d0 + 4 * (tid & 3);
+    const int idx = slot(tid, i), rr = row0 + krow(idx);
+    const uint32_t e0 = (uint32_t)rr * (uint32_t)g.D + (uint32_t)c;
+    float dummy;
+    float4 o;
+    o.x = gate_dp_t<false, DROP, 0>(g, ra4[i].x, 0.f, wc4.x, dsr[i], e0 + 0, thr, dscale, dummy);
+    o.y = gate_dp_t<false, DROP, 0>(g, ra4[i].y, 0.f, wc4.y, dsr[i], e0 + 1, thr, dscale, dummy);
+    o.z = gate_dp_t<false, DROP, 0>(g, ra4[i].z, 0.f, wc4.z, dsr[i], e0 + 2, thr, dscale, dummy);
+    o.w = gate_dp_t<false, DROP, 0>(g, ra4[i].w, 0.f, wc4.w, dsr[i], e0 + 3, thr, dscale, dummy);
+    split_store4(lds + krow(idx) * SROW_F, idx & 3, o);
+  }
+  __device__ inline void store(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) store_piece(lds, i);
+  }
+};
+
 // B[k][n] = rows of Wa / Wb in SplitP_K's k order; the source is k-major, so a thread takes 8 k of one column (SplitM)
-template <int ROWS, int NT>
+template <int ROWS, int NT, bool GATED>
 struct SplitWab_M {
-  static constexpr int TOTAL = ROWS * 2, NV = (TOTAL + NT - 1) / NT;
+  static constexpr int TOTAL = ROWS * 2, NV = (TOTAL + NT - 1) / NT, PIECES = NV;
   static_assert(TOTAL % NT == 0, "whole vector slots only");
   rsrc_t ra, rb;
   int tid;
@@ -345,7 +416,7 @@ struct SplitWab_M {
   __device__ inline void init(const float* wa, const float* wb, int H, int D, int col0, bool) {
     tid = threadIdx.x; hb = (unsigned)H * 4u;
     ra = make_rsrc(wa, (unsigned)D * hb);
-    rb = make_rsrc(wb, (unsigned)D * hb);
+    rb = make_rsrc(GATED ? wb : wa, (unsigned)D * hb);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * NT, c = col0 + idx % ROWS, kh = idx / ROWS;
@@ -353,19 +424,20 @@ struct SplitWab_M {
     }
   }
   __device__ inline void load(int kt) {
-    const bool second = kt & 1;
-    const unsigned soff = (unsigned)((kt >> 1) * SKC) * hb;
+    const bool second = GATED && (kt & 1);
+    const unsigned soff = (unsigned)((GATED ? (kt >> 1) : kt) * SKC) * hb;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[i][j] = bld1(second ? rb : ra, voff[i], soff + (unsigned)j * hb);
   }
+  __device__ inline void store_piece(float* lds, int i) const {
+    const int idx = tid + i * NT;
+    split_store8(lds + (idx % ROWS) * SROW_F, idx / ROWS, r[i]);
+  }
   __device__ inline void store(float* lds) const {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * NT;
-      split_store8(lds + (idx % ROWS) * SROW_F, idx / ROWS, r[i]);
-    }
+    for (int i = 0; i < NV; ++i) store_piece(lds, i);
   }
 };
 
@@ -425,7 +497,10 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   float* ds_l = lds + 2 * T::STAGE_FLOATS;     // [BM] ds, [BM] p, behind the staging buffers (FUSED only)
   float* p_l = ds_l + T::BM;
   MMF_KSTAMP(k0);
-  std::conditional_t<T::SPLIT, SplitP_K<T::BM, T::NT, (T::SPLIT ? MODE : 2)>, LoadP_K<T::BM, T::NT, MODE>> la;
+  constexpr bool SGATED = T::SPLIT && MODE >= 2;
+  std::conditional_t<T::SPLIT,
+                     std::conditional_t<SGATED, SplitP_K<T::BM, T::NT, (SGATED ? MODE : 2)>, SplitP_U<T::BM, T::NT, (T::SPLIT && !SGATED ? MODE : 0)>>,
+                     LoadP_K<T::BM, T::NT, MODE>> la;
   if constexpr (FUSED) {
     // ---- K-prep for this tile's rows: p_i = softmax weight, ds_i = p_i (dM.h_i - dM.M) + gA_i ----------
     // g_i = dM.h_i: every wave takes a contiguous share of the rows; lanes cover float4 pieces of h with 8
@@ -506,14 +581,16 @@ __global__ __launch_bounds__(T::NT) void bwd_dh_kernel(BwdDhParams p) {
   } else {
     la.init(p.g, row0, (int)p.N);
   }
-  std::conditional_t<T::SPLIT, SplitWab_M<T::BN, T::NT>, LoadWab_M<T::BN, T::NT>> lb;
+  std::conditional_t<T::SPLIT, SplitWab_M<T::BN, T::NT, SGATED>, LoadWab_M<T::BN, T::NT>> lb;
   lb.init(p.Wa, p.Wb, p.H, p.g.D, col0, p.g.gated != 0);
   f32x16 acc[T::MB][T::NB];
   f32x4acc acch[T::NB][2];                   // the half block's accumulators (Tile::HALF; unused otherwise)
   const int nk = (p.g.gated ? 2 : 1) * p.g.D / (T::SPLIT ? SKC : KC);
   MMF_KSTAMP(k1);
-  if constexpr (T::SPLIT) {
+  if constexpr (SGATED) {
     dh_split_mainloop<T>(la, lb, nk, lds, acc);
+  } else if constexpr (T::SPLIT) {
+    split_mainloop<T, 4>(la, lb, nk, lds, acc);
   } else if constexpr (T::NT == 256 && T::BM <= 64) {
     if (p.deep && p.g.gated) dh_mainloop_deep<T>(la, lb, nk, lds, acc);       // short grid: see dh_mainloop_deep
     else gemm_mainloop<T, decltype(la), decltype(lb), false>(la, lb, nk, lds, acc);
@@ -1236,9 +1313,9 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
   return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
 }
-// the split-operand K-dh: the training step's shape only (gated stack, fused K-prep, wide tiles)
+// the split-operand K-dh: the training step's shape only (fused K-prep, wide tiles)
 bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {
-  return split && gated && use_wide_tiles(N, H) && (2 * D / SKC) % 4 == 0;
+  return split && use_wide_tiles(N, H) && ((gated ? 2 : 1) * D / SKC) % 4 == 0;
 }
 int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
 
@@ -1259,8 +1336,12 @@ static int launch_bwd_dh_split(BwdDhParams p, hipStream_t st) {
   p.mt_count = (int)((p.N + T::BM - 1) / T::BM); p.nt_count = p.H / 256;
   const int grid = grid_for_tiles(p.mt_count, p.nt_count);
   constexpr int extra = (3 * T::BM + 16) * 4;
-  if (p.g.drop_p > 0.f) return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 3>, p, grid, extra, st);
-  return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 2>, p, grid, extra, st);
+  switch ((p.g.gated ? 2 : 0) + (p.g.drop_p > 0.f ? 1 : 0)) {
+    case 0: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 0>, p, grid, extra, st);
+    case 1: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 1>, p, grid, extra, st);
+    case 2: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 2>, p, grid, extra, st);
+    default: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 3>, p, grid, extra, st);
+  }
 }
 
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {

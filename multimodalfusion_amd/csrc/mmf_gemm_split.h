@@ -61,6 +61,15 @@ __device__ inline void st_u4(float* p, uint32_t a, uint32_t b, uint32_t c, uint3
   *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 }
 #endif
+// Vector slot idx of a k-contiguous chunk image (4 float4 per row) -> tile row.  Not idx / 4: the 16 lanes that share
+// a ds_write_b64 pass must land on 32 distinct banks, and 4 CONSECUTIVE rows do not (row stride 112 bytes = 28 banks:
+// rows r and r + 1 overlap in 4 banks, a 2-way conflict on half of every pass).  Rows r, r + 2, r + 4, r + 6 do
+// (0, 24, 16, 8 mod 32), so lane group g of a wave takes the even or odd rows of one half of the wave's 16 rows.
+// The column piece is idx & 3 either way, so global loads stay 64 contiguous bytes per 4 lanes.
+__device__ inline int krow(int idx) {
+  const int l = idx & 63, g = l >> 4, rsel = (l & 15) >> 2;
+  return (idx >> 6) * 16 + 2 * rsel + (g & 1) + 8 * (g >> 1);
+}
 // 4 consecutive k of one row -> the row's three planes (8 bytes each) at k offset 4 c4
 __device__ inline void split_store4(float* row, int c4, const float4& v) {
   uint32_t a0, a1, a2, b0, b1, b2;
@@ -106,7 +115,7 @@ struct SplitK {
     tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = slot(tid, i), rr = row0 + (idx >> 2);
+      const int idx = slot(tid, i), rr = row0 + krow(idx);
       voff[i] = rr < nrows ? ((unsigned)rr * (unsigned)ld + 4u * (idx & 3)) * 4u : OOB;
     }
   }
@@ -121,19 +130,19 @@ struct SplitK {
   static constexpr int PIECES = NV;
   __device__ inline void store_piece(float* lds, int i) const {
     const int idx = slot(tid, i);
-    split_store4(lds + (idx >> 2) * SROW_F, idx & 3, r[i]);
+    split_store4(lds + krow(idx) * SROW_F, idx & 3, r[i]);
   }
   __device__ inline void store(float* lds) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = slot(tid, i);
 #ifdef MMF_SDIAG_NOSPLIT       /* LDS writes of unsplit data: the staging path without its VALU work */
-      st_u2(lds + (idx >> 2) * SROW_F + 2 * (idx & 3), __float_as_uint(r[i].x), __float_as_uint(r[i].y));
-      st_u2(lds + (idx >> 2) * SROW_F + 8 + 2 * (idx & 3), __float_as_uint(r[i].z), __float_as_uint(r[i].w));
-      st_u2(lds + (idx >> 2) * SROW_F + 16 + 2 * (idx & 3), __float_as_uint(r[i].x), __float_as_uint(r[i].w));
+      st_u2(lds + krow(idx) * SROW_F + 2 * (idx & 3), __float_as_uint(r[i].x), __float_as_uint(r[i].y));
+      st_u2(lds + krow(idx) * SROW_F + 8 + 2 * (idx & 3), __float_as_uint(r[i].z), __float_as_uint(r[i].w));
+      st_u2(lds + krow(idx) * SROW_F + 16 + 2 * (idx & 3), __float_as_uint(r[i].x), __float_as_uint(r[i].w));
       continue;
 #endif
-      split_store4(lds + (idx >> 2) * SROW_F, idx & 3, r[i]);
+      split_store4(lds + krow(idx) * SROW_F, idx & 3, r[i]);
     }
   }
 };
@@ -155,7 +164,7 @@ struct SplitGateW {
     rb = make_rsrc(GATED ? wb : wa, (unsigned)D * (unsigned)H * 4u);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * NT, j = idx >> 2;
+      const int idx = tid + i * NT, j = krow(idx);
       int w, d;
       if (!GATED) { w = 0; d = d0 + j; }
       else { w = (j >> 5) & 1; d = d0 + (j >> 6) * 32 + (j & 31); }
@@ -171,7 +180,7 @@ struct SplitGateW {
   static constexpr int PIECES = NV;
   __device__ inline void store_piece(float* lds, int i) const {
     const int idx = tid + i * NT;
-    split_store4(lds + (idx >> 2) * SROW_F, idx & 3, r[i]);
+    split_store4(lds + krow(idx) * SROW_F, idx & 3, r[i]);
   }
   __device__ inline void store(float* lds) const {
 #pragma unroll

@@ -30,16 +30,18 @@ def _case(N, gated=True, dropout=False, train=True, size="small"):
                 train=train, seed=4200 + N, x_seed=5200 + N, mask_seed=4321)
 
 
-@pytest.mark.parametrize("N,dropout,train,size", [
-    (16421, False, True, "small"),     # smallest bags on the split tiles, ragged last tile, one dropout site
-    (23333, True, True, "small"),      # + attention dropout: the (gated, dropout) instantiations of K-dh and K-tn
-    (20011, False, False, "small"),    # eval mode
-    (17011, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile in K-dh, three gate tiles in K-tn
+@pytest.mark.parametrize("N,gated,dropout,train,size", [
+    (16421, True, False, True, "small"),     # smallest bags on the split tiles, ragged last tile, one dropout site
+    (23333, True, True, True, "small"),      # + attention dropout: the (gated, dropout) instantiations of K-dh and K-tn
+    (20011, True, False, False, "small"),    # eval mode
+    (17011, True, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile in K-dh, three gate tiles in K-tn
+    (16999, False, False, True, "small"),    # Attn_Net (ungated: the reference's CLI default): one-part K-dh ring, 256-dim TN gate tiles
+    (19999, False, True, True, "small"),     # ungated + attention dropout
 ])
-def test_split_against_fp64_oracle(N, dropout, train, size, split_mode, monkeypatch):
-    m = _case(N, dropout=dropout, train=train, size=size)
+def test_split_against_fp64_oracle(N, gated, dropout, train, size, split_mode, monkeypatch):
+    m = _case(N, gated=gated, dropout=dropout, train=train, size=size)
     sd, x, _ = cases.path_inputs(m)
-    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"bf16x3 N={N} dropout={dropout} train={train} {size}",
+    compare(run_path_hip(m, monkeypatch), cases.run_path(m), f"bf16x3 N={N} gated={gated} dropout={dropout} train={train} {size}",
             kink_units=relu_kink_units(sd, x))
 
 
