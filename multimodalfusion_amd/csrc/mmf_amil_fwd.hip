@@ -731,9 +731,9 @@ static int launch_linear_wide(LinearParams p, hipStream_t st) {
   return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
-template <int ROWS, int WM, int WN>
+template <int ROWS, int WM, int WN, int GM = 1>
 static int launch_linear_split(LinearParams p, hipStream_t st) {
-  using T = TileSp<ROWS, 256, WM, WN>;
+  using T = TileSp<ROWS, 256, WM, WN, GM>;
   p.mt_count = (int)((p.M + T::BM - 1) / T::BM); p.nt_count = p.N / 256;
   return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
@@ -744,6 +744,8 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (p.M <= 0) return MMF_OK;
   if (p.split && use_wide_tiles(p.M, p.N) && p.K % (4 * SKC) == 0 && p.nseg == 1) {
     static const int rows = getenv("MMF_SPLIT_ROWS") ? atoi(getenv("MMF_SPLIT_ROWS")) : 224;
+    static const int gm = getenv("MMF_SPLIT_GM") ? atoi(getenv("MMF_SPLIT_GM")) : 1;      // A/B switch
+    if (gm == 2 && rows == 224) return launch_linear_split<224, 1, 8, 2>(p, st);
     if (rows == 256) return launch_linear_split<256, 2, 4>(p, st);
     if (rows == 192) return launch_linear_split<192, 1, 8>(p, st);
     return launch_linear_split<224, 1, 8>(p, st);

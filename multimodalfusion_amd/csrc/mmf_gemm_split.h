@@ -27,9 +27,9 @@ constexpr int SKC = 16;           // fp32 k-values per staged chunk
 constexpr int SROW = 112;         // bytes per LDS row
 constexpr int SROW_F = SROW / 4;
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int GM_ = 1>
 struct TileSp {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, GM = GM_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int MB = BM / WM / 32, NB = BN / WN / 32;
   static constexpr bool HALF = false, SPLIT = true, PERM = false;
@@ -250,7 +250,7 @@ __device__ inline f32x16 mfma_bf(const f32x4& a, const f32x4& b, const f32x16& c
 // of group s+1 are read while the 6 GM NB MFMAs of group s issue.  hook(s) runs in
 // front of group s's MFMAs: the main loop spreads the staging of later chunks over it.
 template <class T>
-constexpr int split_gm() { return 1; }
+constexpr int split_gm() { return T::GM; }
 template <class T>
 constexpr int split_steps() { return (T::MB + split_gm<T>() - 1) / split_gm<T>(); }
 

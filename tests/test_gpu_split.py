@@ -45,6 +45,17 @@ def test_split_against_fp64_oracle(N, gated, dropout, train, size, split_mode, m
             kink_units=relu_kink_units(sd, x))
 
 
+def test_split_config4_mm_with_50k_path_bag(split_mode):
+    """BASELINE config 4 at its full size in this mode: the multimodal head (concat fusion) with a 50,000 x 1024 fp32 path
+    bag (the path stack on the split kernels; the 512-instance radio bags stay on the exact-fp32 small tiles) against the
+    fp64 autograd oracle."""
+    from test_gpu_omic_mm import run_mm_hip
+    m = dict(fusion="concat", mode="radio_path_omic", Np=50_000, nr=512, G=80, gate_path=True, gate_radio=True, K=4,
+             seed=404, x_seed=405, y=1, c=0, alpha=0.0, bias_std=0.02)
+    sd, xs, xp, xo = cases.mm_inputs(m)
+    compare(run_mm_hip(m), cases.run_mm(m), "bf16x3 config4 concat", kink_units=relu_kink_units(sd, xp))
+
+
 def test_split_kernels_are_the_ones_that_ran(split_mode, monkeypatch):
     """The mode must not silently fall back: the kernel trace of a step on a large gated bag names the split kernels."""
     from multimodalfusion_amd._lib import KernelTrace
