@@ -238,6 +238,11 @@ struct SplitM {
 struct FragS { f32x4 p[3]; };        // a row's three plane halves (8 bf16 each) for one lane
 
 __device__ inline void read_frag(const float* row, FragS& f) {
+#ifdef MMF_SDIAG_NOFRAG        /* diagnostic build: fragments come from registers, not LDS (results are wrong) */
+#pragma unroll
+  for (int q = 0; q < 3; ++q) f.p[q] = f32x4{(float)(size_t)row, 1.f, 2.f, (float)q};
+  return;
+#endif
 #pragma unroll
   for (int q = 0; q < 3; ++q) f.p[q] = *reinterpret_cast<const f32x4*>(row + 8 * q);
 }
@@ -344,9 +349,13 @@ __device__ inline void split_mainloop(LA& la0, const LB& lb0, int nk, float* lds
         if (s == 0) la[j].load(kt + D);
         if (s == (NS >= 2 ? 1 : 0)) lb[j].load(kt + D);
         constexpr int PA = LA::PIECES, PT = LA::PIECES + LB::PIECES;
+        // D = 2 (the TN kernel: no registers for a deeper ring): the pieces go to the LAST steps, so that a request has
+        // 1.5+ chunks to land instead of 1 -- with the pieces up front the whole workgroup waited at the barrier for
+        // its slowest load (no-barrier diagnostic build: 207 -> 180 us)
+        constexpr bool LATE = D == 2 && PT <= NS;
 #pragma unroll
         for (int q = 0; q < PT; ++q)
-          if (s == q * NS / PT) {
+          if (s == (LATE ? NS - PT + q : q * NS / PT)) {
             if (q < PA) la[(j + 1) % D].store_piece(nxt, q);
             else lb[(j + 1) % D].store_piece(nxt + T::A_FLOATS, q - PA);
           }

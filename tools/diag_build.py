@@ -30,7 +30,8 @@ VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "epi1": ["-DMMF_DIAG_EPI1"], "nogload": ["-DMMF_DIAG_NOGLOAD"],
             "nobar": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR"],
             "s_nomfma": ["-DMMF_SDIAG_NOMFMA"], "s_nostage": ["-DMMF_SDIAG_NOSTAGE"], "s_nogload": ["-DMMF_SDIAG_NOGLOAD"],
-            "s_nosplit": ["-DMMF_SDIAG_NOSPLIT"], "s_noldsw": ["-DMMF_SDIAG_NOLDSW"], "s_nobar": ["-DMMF_SDIAG_NOSTAGE", "-DMMF_SDIAG_NOBAR"],
+            "s_nosplit": ["-DMMF_SDIAG_NOSPLIT"], "s_noldsw": ["-DMMF_SDIAG_NOLDSW"], "s_nobar2": ["-DMMF_SDIAG_NOBAR"], "s_nofrag": ["-DMMF_SDIAG_NOFRAG"],
+            "s_nofragbar": ["-DMMF_SDIAG_NOFRAG", "-DMMF_SDIAG_NOBAR"], "s_nobar": ["-DMMF_SDIAG_NOSTAGE", "-DMMF_SDIAG_NOBAR"],
             "nosched": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG", "-DMMF_DIAG_NOBAR", "-DMMF_DIAG_NOSCHED"]}
 
 
