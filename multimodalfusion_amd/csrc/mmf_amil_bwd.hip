@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(T::NT) void tn_kernel(TnParams p) {
     std::conditional_t<T::SPLIT, SplitA_M_Plain<T::BM, T::NT>, LoadA_M_Plain<T::BM, T::NT>> la;
     la.init(q.A, q.lda, tm * T::BM, q.M, kbase, kmax, do_sum);
     f32x16 acc[T::MB][T::NB];
-    if constexpr (T::SPLIT) split_mainloop<T, 2>(la, lb, nk, lds, acc);
+    if constexpr (T::SPLIT) split_mainloop<T, 2, decltype(la), decltype(lb), true>(la, lb, nk, lds, acc);
     else gemm_mainloop<T>(la, lb, nk, lds, acc, nullptr, last_groups);
     tn_store<T>(q, split, tn, acc, lds, [&](int r) { const int row = tm * T::BM + r; return row < q.M ? row : -1; });
     if (do_sum) {

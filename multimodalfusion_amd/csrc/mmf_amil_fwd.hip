@@ -169,7 +169,7 @@ __global__ __launch_bounds__(T::NT) void linear_nt_split_kernel(LinearParams p) 
   SplitK<T::BN, T::NT> lb;
   lb.init(p.w, p.K, col0, p.N);
   f32x16 acc[T::MB][T::NB];
-  split_mainloop<T, 4>(la, lb, p.K / SKC, lds, acc);
+  split_mainloop<T, 4, decltype(la), decltype(lb), true>(la, lb, p.K / SKC, lds, acc);
   const bool drop = p.drop_p > 0.f;
   if (p.act == ACT_RELU) {
     if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, nullptr, lds, row0, col0);

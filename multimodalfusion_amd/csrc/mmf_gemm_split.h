@@ -311,7 +311,9 @@ struct has_absorb : std::false_type {};
 template <class L>
 struct has_absorb<L, std::void_t<decltype(std::declval<L&>().absorb(std::declval<const L&>()))>> : std::true_type {};
 
-template <class T, int D, class LA, class LB>
+// STAMP (diagnostic -DMMF_STAMPS builds only): per wave, s_memtime ticks inside the chunks' work and at their barriers,
+// summed into g_stamps[0 / 1] (waves 0-3) and [2 / 3] (waves 4-7), chunk count in [4]
+template <class T, int D, class LA, class LB, bool STAMP = false>
 __device__ inline void split_mainloop(LA& la0, const LB& lb0, int nk, float* lds, f32x16 (&acc)[T::MB][T::NB]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
@@ -334,12 +336,19 @@ __device__ inline void split_mainloop(LA& la0, const LB& lb0, int nk, float* lds
   __syncthreads();
   constexpr int NS = split_steps<T>();
   static_assert((D & 1) == 0, "an even D keeps the LDS stage of copy j fixed");
+#ifdef MMF_STAMPS
+  unsigned long long st_work = 0, st_bar = 0;
+#endif
   for (int kt0 = 0; kt0 < nk; kt0 += D) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       const int kt = kt0 + j;
       float* cur = lds + (j & 1) * T::STAGE_FLOATS;
       float* nxt = lds + ((j + 1) & 1) * T::STAGE_FLOATS;
+#ifdef MMF_STAMPS
+      unsigned long long st0 = 0;
+      if constexpr (STAMP) st0 = stamp_now();
+#endif
       compute_chunk_split<T>(cur, cur + T::A_FLOATS, acc, wm, wn, lane, [&](int s) {
 #ifdef MMF_SDIAG_NOSTAGE
         return;
@@ -360,11 +369,27 @@ __device__ inline void split_mainloop(LA& la0, const LB& lb0, int nk, float* lds
             else lb[(j + 1) % D].store_piece(nxt + T::A_FLOATS, q - PA);
           }
       });
+#ifdef MMF_STAMPS
+      unsigned long long st1 = 0;
+      if constexpr (STAMP) st1 = stamp_now();
+#endif
 #ifndef MMF_SDIAG_NOBAR
       __syncthreads();
 #endif
+#ifdef MMF_STAMPS
+      if constexpr (STAMP) { st_work += st1 - st0; st_bar += stamp_now() - st1; }
+#endif
     }
   }
+#ifdef MMF_STAMPS
+  if constexpr (STAMP) {
+    if (lane == 0) {
+      const int grp = wave >= 4 ? 2 : 0;
+      atomicAdd(&g_stamps[grp], st_work); atomicAdd(&g_stamps[grp + 1], st_bar);
+      if (wave == 0) atomicAdd(&g_stamps[4], (unsigned long long)nk);
+    }
+  }
+#endif
   if constexpr (has_absorb<LA>::value) {
 #pragma unroll
     for (int j = 0; j < D; ++j) la0.absorb(la[j]);
