@@ -350,6 +350,14 @@ def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
         d1 = time_steps(one, steps, warmup, 1)
         prof = kernel_profile(one, max(5, min(steps, 20)))
         dn = time_steps(make_step_inflight(model, x, dev, 1, inflight), steps, warmup, 1)
+        sizes = {}
+        if N == 50000:                  # north_star's other bag sizes in this mode (64-row split tiles below 16,384 instances)
+            g = torch.Generator(device=dev)
+            g.manual_seed(4321)
+            for n2 in (1000, 10000):
+                x2 = torch.randn(n2, 1024, device=dev, generator=g)
+                d2 = time_steps(make_step(model, x2, dev, None, 1), max(steps, 100), warmup, 1)
+                sizes[str(n2)] = {"ms_per_step": 1e3 * d2 / max(steps, 100), "bags_per_s": max(steps, 100) / d2}
     finally:
         ops.set_gemm(prev)
         for p in model.parameters():
@@ -361,7 +369,7 @@ def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
             "value_one_bag_per_step": steps / d1, "ms_per_step_one_bag": ms1,
             "value": steps / dn, "bags_in_flight": inflight,
             "whole_step_x_fp32_mfma_peak": flops_per_bag(N) / (ms1 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "roofline": roofline_of(prof, N, False),
+            "roofline": roofline_of(prof, N, False), "other_sizes": sizes,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())}}
 
 

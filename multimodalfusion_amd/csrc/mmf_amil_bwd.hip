@@ -407,14 +407,16 @@ struct SplitP_U {
 template <int ROWS, int NT, bool GATED>
 struct SplitWab_M {
   static constexpr int TOTAL = ROWS * 2, NV = (TOTAL + NT - 1) / NT, PIECES = NV;
-  static_assert(TOTAL % NT == 0, "whole vector slots only");
+  static_assert(TOTAL % NT == 0 || TOTAL < NT, "whole vector slots only");
   rsrc_t ra, rb;
   int tid;
   unsigned hb;
   unsigned voff[NV];
   float r[NV][8];
   __device__ inline void init(const float* wa, const float* wb, int H, int D, int col0, bool) {
-    tid = threadIdx.x; hb = (unsigned)H * 4u;
+    // fewer (column, k half) items than threads (64-column tiles): the upper threads repeat the lower ones' work --
+    // same addresses, same data, same LDS destinations, no branch in load() / store()
+    tid = TOTAL < NT ? (int)threadIdx.x % TOTAL : (int)threadIdx.x; hb = (unsigned)H * 4u;
     ra = make_rsrc(wa, (unsigned)D * hb);
     rb = make_rsrc(GATED ? wb : wa, (unsigned)D * hb);
 #pragma unroll
@@ -1344,10 +1346,36 @@ static int launch_bwd_dh_split(BwdDhParams p, hipStream_t st) {
   }
 }
 
+// 64 x 64 split tiles for bags below the wide tiles (with or without the fused K-prep)
+static int launch_bwd_dh_split_small(BwdDhParams p, hipStream_t st) {
+  using T = TileSp<64, 64, 2, 2>;
+  p.mt_count = (int)((p.N + 63) / 64); p.nt_count = (p.H + 63) / 64;
+  const int grid = grid_for_tiles(p.mt_count, p.nt_count);
+  constexpr int extra = (3 * T::BM + 16) * 4;
+  const int mode = (p.g.gated ? 2 : 0) + (p.g.drop_p > 0.f ? 1 : 0);
+  if (p.fused_prep) {
+    switch (mode) {
+      case 0: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 0>, p, grid, extra, st);
+      case 1: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 1>, p, grid, extra, st);
+      case 2: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 2>, p, grid, extra, st);
+      default: return launch_tiled_extra<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, true, 3>, p, grid, extra, st);
+    }
+  }
+  switch (mode) {
+    case 0: return launch_tiled<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, false, 0>, p, grid, st);
+    case 1: return launch_tiled<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, false, 1>, p, grid, st);
+    case 2: return launch_tiled<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, false, 2>, p, grid, st);
+    default: return launch_tiled<T>("bwd_dh_split_kernel", bwd_dh_kernel<T, false, 3>, p, grid, st);
+  }
+}
+
 int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
   if (p.fused_prep && bwd_dh_split_ok(p.N, p.H, p.g.D, p.g.gated, p.split)) return launch_bwd_dh_split<224>(p, st);
+  if (p.split && !use_wide_tiles(p.N, p.H) && (p.N / 128) * ((p.H + 127) / 128) < 256 && p.N >= split_min_rows() &&
+      ((p.g.gated ? 2 : 1) * p.g.D / SKC) % 4 == 0 && (!p.fused_prep || dh_short_grid(p.N, p.H)))
+    return launch_bwd_dh_split_small(p, st);
   if (use_wide_tiles(p.N, p.H)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
@@ -1411,7 +1439,7 @@ int tn_splits(int64_t K, int total_tiles, int tile) {
 // the large-bag tile is instantiated per attention-dropout state (no per-element test in the gate tiles' staging path)
 template <class T>
 static int launch_tn_grid(const TnParams& p, int grid, hipStream_t st) {
-  if constexpr (T::BM == 256) {
+  if constexpr (T::BM == 256 || T::SPLIT) {
     const char* name = T::SPLIT ? "tn_split_kernel" : "tn_kernel";
     if (p.g.drop_p > 0.f) return launch_tiled<T>(name, tn_kernel<T, 1>, p, grid, st);
     return launch_tiled<T>(name, tn_kernel<T, 0>, p, grid, st);
@@ -1484,6 +1512,7 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
 int launch_tn(TnParams p, hipStream_t st) {
   if (p.tile == 256 && p.split) return launch_tn_t<TileSp<256, 256, 2, 4>>(p, st);
   if (p.tile == 256) return launch_tn_t<Tile<256, 256, 2, 4, false, false, 2>>(p, st);
+  if (p.split && p.K >= split_min_rows()) return launch_tn_t<TileSp<128, 128, 2, 2>>(p, st);
   return launch_tn_t<Tile<128, 128, 2, 2, false, false, 2>>(p, st);
 }
 

@@ -615,8 +615,8 @@ __global__ __launch_bounds__(1024) void pool_merge_kernel(PoolParams p) {
   if (blockIdx.x == 0 && tid == 0) { p.stats[0] = m; p.stats[1] = l; }
 }
 
-// The head tail as its own single-workgroup launch behind K-merge (HeadTail).  Small bags (n_groups <= TAIL_MERGE_MAX
-// partials) are merged right here as well, one launch less: thread c sums column c over the groups.
+// The head tail as its own single-workgroup launch behind K-merge (HeadTail).  It can also merge up to TAIL_MERGE_MAX
+// partials itself (thread c sums column c over the groups: one launch less) -- off by default, see launch_pool_merge.
 // (First version: tail run by the LAST workgroup of K-merge, found with a ticket counter -- the fences, the atomic and
 // the re-read of M through L2 cost 12 us, more than the 5 us of this launch.)
 constexpr int TAIL_MERGE_MAX = 64;
@@ -731,6 +731,13 @@ static int launch_linear_wide(LinearParams p, hipStream_t st) {
   return launch_tiled<T>("linear_nt_kernel", linear_nt_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
+int split_min_rows() {
+  // measured one bag per step, exact fp32 -> bf16x3: 1k 0.101 -> 0.096 ms, 2k 0.115 -> 0.106, 4,096 0.137 -> 0.127,
+  // 6k 0.165 -> 0.140, 10k 0.235 -> 0.190, 14k 0.285 -> 0.235 (profiles/r02/d_split_sizes.txt): never slower; below
+  // 1,024 instances the step is a dozen launch latencies and stays on the exact kernels
+  static const int env = getenv("MMF_SPLIT_MIN") ? atoi(getenv("MMF_SPLIT_MIN")) : 1024;   // tuning override
+  return env;
+}
 template <int ROWS, int WM, int WN, int GM = 1>
 static int launch_linear_split(LinearParams p, hipStream_t st) {
   using T = TileSp<ROWS, 256, WM, WN, GM>;
@@ -764,6 +771,10 @@ int launch_linear(LinearParams p, hipStream_t st) {
     return launch_tiled<TileNT128>("linear_nt_kernel", linear_nt_kernel<TileNT128>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
   p.mt_count = (int)((p.M + 63) / 64); p.nt_count = (p.N + 63) / 64;
+  if (p.split && p.nseg == 1 && p.K % (4 * SKC) == 0 && p.M >= split_min_rows()) {
+    using T = TileSp<64, 64, 2, 2>;
+    return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  }
   p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && p.nseg == 1 ? 1 : 0;
   return launch_tiled<TileNT64>("linear_nt_kernel", linear_nt_kernel<TileNT64>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
@@ -781,8 +792,16 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   p.nt_count = gate_parts(p.D, p.gated, p.N);
   p.row_begin = 0; p.row_end = p.N;
   using TS = Tile<64, 128, 2, 2, true, true>;
+  using SB = TileSp<128, 128, 2, 2>;
+  using SS = TileSp<64, 128, 2, 2>;
+  const bool split = p.split && p.H % (4 * SKC) == 0;
   auto small = [&](GateFwdParams q) {
     q.mt_count = (int)((q.row_end - q.row_begin + 63) / 64);
+    if (split && q.N >= split_min_rows()) {
+      const int grid = grid_for_tiles(q.mt_count, q.nt_count);
+      return q.gated ? launch_tiled<SS>("gate_fwd_split_kernel", gate_fwd_kernel<SS, true>, q, grid, st)
+                     : launch_tiled<SS>("gate_fwd_split_kernel", gate_fwd_kernel<SS, false>, q, grid, st);
+    }
     q.deep = short_grid(q.mt_count * q.nt_count) && (q.H / KC) % 4 == 0 ? 1 : 0;
     const int grid = grid_for_tiles(q.mt_count, q.nt_count);
     return q.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, q, grid, st)
@@ -802,9 +821,6 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   //   D  256 short tiles         -> slot 2's last, so that both slots end at R T
   //   E  the remaining rows as short tiles (twice as many CUs work on them, each for half the time)
   // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
-  using SB = TileSp<128, 128, 2, 2>;
-  using SS = TileSp<64, 128, 2, 2>;
-  const bool split = p.split && p.H % (4 * SKC) == 0;
   static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
   int64_t mt = (p.N + 127) / 128;
   const int64_t slots = 512, total = mt * p.nt_count;
@@ -869,7 +885,11 @@ int launch_pool(PoolParams p, hipStream_t st) {
 int launch_pool_merge(PoolParams p, hipStream_t st) {
   if (p.n_groups < 1 || p.n_groups > MERGE_MAX_GROUPS || p.H > 1024 || p.H % 32 != 0) return MMF_ERR_SHAPE;
   if (p.tail.Wk && (p.tail.K < 1 || p.tail.K > 32)) return MMF_ERR_SHAPE;
-  p.merge_in_tail = p.tail.Wk && p.n_groups <= TAIL_MERGE_MAX ? 1 : 0;
+  // Merging inside the single-workgroup tail kernel saves a launch and loses more than that: measured, one bag per
+  // step, separate merge vs merge in the tail: 1k 0.0995 vs 0.1016 ms, 2k 0.1085 vs 0.1146, 4,096 (64 groups) 0.1236 vs
+  // 0.1370.  Off by default; MMF_TAIL_MERGE=<max groups, <= 64> turns it back on.
+  static const int tail_merge = getenv("MMF_TAIL_MERGE") ? atoi(getenv("MMF_TAIL_MERGE")) : 0;
+  p.merge_in_tail = p.tail.Wk && p.n_groups <= (tail_merge < TAIL_MERGE_MAX ? tail_merge : TAIL_MERGE_MAX) ? 1 : 0;
   if (!p.merge_in_tail) {
     ProfScope ps("pool_merge_kernel", st);
     hipLaunchKernelGGL(pool_merge_kernel, dim3(p.H / 32), dim3(1024), 0, st, p);

@@ -103,7 +103,8 @@ def test_path_golden_cases(golden, monkeypatch):
             continue
         res = run_path_hip(m, monkeypatch)
         ref = cases.run_path(m)
-        compare(res, ref, name)
+        sd, x, _ = cases.path_inputs(m)
+        compare(res, ref, name, kink_units=relu_kink_units(sd, x))
         tag = name + "/f64"
         assert abs(res["loss"] - float(g[tag + "/loss"])) <= 1e-5
         np.testing.assert_allclose(res["hazards"], g[tag + "/hazards"], rtol=0, atol=1e-4)
