@@ -1313,7 +1313,8 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 
 // > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
 static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
-  return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= 512;
+  static const int cap = getenv("MMF_DH_SHORT_MAX") ? atoi(getenv("MMF_DH_SHORT_MAX")) : 512;   // tuning override
+  return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= cap;
 }
 // the split-operand K-dh: the training step's shape only (fused K-prep, wide tiles)
 bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {

@@ -12,3 +12,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_G
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/d_pmc_FETCH_SIZE $R/gpurun_out/d_pmc_WRITE_SIZE "$R/gpurun_out/d_pmc_SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES+GRBM_GUI_ACTIVE" > $R/gpurun_out/d_pmc_bf16x3_50000.txt
 cat $R/gpurun_out/d_kstats_bf16x3_50000.txt $R/gpurun_out/d_pmc_bf16x3_50000.txt
+# the 10k bag (64-row split tiles, 128x128 split-K tile): kernel stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/d_trace_10k -- python3 $R/tools/step_profile.py 10000 200 f32 > $R/gpurun_out/d_trace_10k.log 2>&1 || exit 1
+python3 $R/tools/kstats.py $R/gpurun_out/d_trace_10k > $R/gpurun_out/d_kstats_bf16x3_10000.txt
+cat $R/gpurun_out/d_kstats_bf16x3_10000.txt
