@@ -9,7 +9,8 @@
 // Six bf16 MFMAs replace one fp32 MFMA's worth of k: 2.67 x the exact instruction's rate.  Error against an fp64
 // product: the same as the exact-fp32 instruction's (measured on the path's shapes: tests/test_gpu_split.py,
 // DESIGN.md 7d) -- the accumulation is fp32 either way and dominates.
-// Not representable: |a| within one bf16 ulp of FLT_MAX (bf16(a) rounds to inf); inf inputs give NaN instead of inf.
+// Not representable: |a| within one bf16 ulp of FLT_MAX (bf16(a) rounds to inf); inf inputs give NaN instead of inf;
+// below 2^-110 the low planes underflow (absolute error < 2^-126).  tests/test_split_math_cpu.py restates the arithmetic.
 //
 // Layout: operands are staged through LDS in chunks of SKC = 16 k-values.  An LDS row (one tile row / column) holds
 // the chunk's three planes back to back, [a0: 16 bf16 | a1 | a2] = 96 bytes, padded to 112 (7 16-byte slots, odd, so
