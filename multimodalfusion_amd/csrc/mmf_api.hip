@@ -171,6 +171,7 @@ static int check_desc(const mmf_amil_desc* d, int elem_bytes = 4) {
   const int64_t widest = d->L > 2 * d->D ? d->L : 2 * d->D;
   if (d->N * widest * elem_bytes >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
   if (d->p_h < 0.f || d->p_h >= 1.f || d->p_att < 0.f || d->p_att >= 1.f) return MMF_ERR_ARG;
+  if (d->gemm != MMF_GEMM_F32 && d->gemm != MMF_GEMM_BF16X3) return MMF_ERR_ARG;
   return MMF_OK;
 }
 

@@ -116,3 +116,15 @@ def test_split_error_matches_exact_fp32(monkeypatch):
         report[k] = (e0, e1)
         assert e1 <= 2 * e0 + 2e-7 * max(float(np.abs(g).max()), 1e-30), (k, e0, e1)
     print("max abs error vs fp64 (exact fp32, bf16x3):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
+
+
+def test_unknown_gemm_mode_is_refused():
+    """mmf_amil_desc::gemm takes 0 or 1; anything else is an argument error, not a silent default."""
+    from multimodalfusion_amd import ops
+    from multimodalfusion_amd._lib import MmfError
+    prev = ops.set_gemm(7)
+    try:
+        with pytest.raises(MmfError):
+            run_path_hip(_case(300, train=False))
+    finally:
+        ops.set_gemm(prev)
