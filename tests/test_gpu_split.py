@@ -118,6 +118,15 @@ def test_split_error_matches_exact_fp32(monkeypatch):
     print("max abs error vs fp64 (exact fp32, bf16x3):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in report.items()})
 
 
+def test_split_size_independent_properties_at_full_size(split_mode):
+    """The oracle-free checks of tests/test_gpu_path.py in this mode: permutation / shift invariance, the softmax spike,
+    and the 50,000 x 1024 BASELINE bag's linearity / finiteness / softmax-mass properties."""
+    import test_gpu_path as P
+    P.test_permutation_and_shift_invariance()
+    P.test_softmax_spike_forces_rescale()
+    P.test_full_size_50k_properties()
+
+
 def test_unknown_gemm_mode_is_refused():
     """mmf_amil_desc::gemm takes 0 or 1; anything else is an argument error, not a silent default."""
     from multimodalfusion_amd import ops
