@@ -733,9 +733,11 @@ static int launch_linear_wide(LinearParams p, hipStream_t st) {
 
 int split_min_rows() {
   // measured one bag per step, exact fp32 -> bf16x3: 1k 0.101 -> 0.096 ms, 2k 0.115 -> 0.106, 4,096 0.137 -> 0.127,
-  // 6k 0.165 -> 0.140, 10k 0.235 -> 0.190, 14k 0.285 -> 0.235 (profiles/r02/d_split_sizes.txt): never slower; below
-  // 1,024 instances the step is a dozen launch latencies and stays on the exact kernels
-  static const int env = getenv("MMF_SPLIT_MIN") ? atoi(getenv("MMF_SPLIT_MIN")) : 1024;   // tuning override
+  // 6k 0.165 -> 0.140, 10k 0.235 -> 0.190, 14k 0.285 -> 0.235 (profiles/r02/d_split_sizes.txt): never slower.  Default 1:
+  // every bag takes the split tiles, so that an instance's score does not depend on the size of the bag it is scored
+  // in, bit for bit (heat-map batches of 512 patches vs the whole slide: tests/test_gpu_infer.py) -- the accumulation
+  // order is the same on every split tile shape, but not between a split tile and an exact-fp32 one
+  static const int env = getenv("MMF_SPLIT_MIN") ? atoi(getenv("MMF_SPLIT_MIN")) : 1;   // tuning override
   return env;
 }
 template <int ROWS, int WM, int WN, int GM = 1>

@@ -227,7 +227,7 @@ int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);
 // split-operand mode on bags below the wide tiles: instances from which the small split tiles (64-row GEMM tiles, 128 x 128
-// TN tile) are taken instead of the exact-fp32 ones (1,024; below it a step is a dozen launch latencies)
+// TN tile) are taken instead of the exact-fp32 ones (default 1: every bag, which keeps an instance's score independent of its bag's size)
 int split_min_rows();
 int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);

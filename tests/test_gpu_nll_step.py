@@ -9,7 +9,7 @@ import torch
 
 from oracle import bf16_port, cases
 from test_gpu_bf16 import compare_bf16
-from test_gpu_path import DEV, _grads, _load, _t, compare, run_path_hip
+from test_gpu_path import DEV, _grads, _load, _t, compare, relu_kink_units, run_path_hip
 
 pytestmark = pytest.mark.gpu
 
@@ -121,7 +121,8 @@ def test_step_big_model_all_dropout_sites(gated, dropout, monkeypatch):
     m = dict(N=5003, gated=gated, size="big", K=8, dropout=dropout, y=6, c=1, alpha=0.25, bias_std=0.05, train=True,
              seed=8100, x_seed=8200, mask_seed=8300)
     res, _ = run_step(m, monkeypatch)
-    compare(res, cases.run_path(m), f"step big gated={gated}")
+    sd, x, _ = cases.path_inputs(m)
+    compare(res, cases.run_path(m), f"step big gated={gated}", kink_units=relu_kink_units(sd, x))
 
 
 def test_step_bf16_full_size_100k(monkeypatch):

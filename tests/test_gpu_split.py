@@ -3,8 +3,8 @@ the bf16 matrix cores with every fp32 operand split into three bf16 values (six 
 
 Two bars:
   * the same bars as the exact-fp32 path (tests/test_gpu_path.py) against the live fp64 oracle, on bags that take the
-    split tiles (wide row tiles + 256x256 split-K tile from 16,384 instances, 64-row tiles + 128x128 split-K tile from
-    1,024), ragged, with and without the dropout sites;
+    split tiles (wide row tiles + 256x256 split-K tile from 16,384 instances, 64-row tiles + 128x128 split-K tile
+    below), ragged, with and without the dropout sites;
   * the claim the mode rests on -- fp32-equivalent accuracy: its error against the fp64 oracle is compared with the
     exact-fp32 path's error on the same inputs, output by output (it must not exceed 2 x that error + rounding noise).
 """
@@ -36,7 +36,8 @@ def _case(N, gated=True, dropout=False, train=True, size="small"):
     (23333, True, True, True, "small"),      # + attention dropout: the (gated, dropout) instantiations of K-dh and K-tn
     (20011, True, False, False, "small"),    # eval mode
     (17011, True, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile in K-dh, three gate tiles in K-tn
-    (1100, True, True, True, "small"),       # the smallest bags the mode takes: 18 row tiles of 64, ragged
+    (77, True, True, True, "small"),         # two ragged 64-row tiles
+    (1100, True, True, True, "small"),       # 18 row tiles of 64, ragged
     (4099, True, True, True, "small"),       # below the wide tiles: 64-row split GEMM tiles, 128 x 128 split TN tile, fused K-prep
     (10000, True, False, True, "small"),     # BASELINE's 10k bag: K-prep as its own launch beside the 64-row split K-dh
     (5003, False, True, True, "big"),        # small tiles, ungated, big model: 8 column tiles in K-dh, 64-dim TN gate tiles
@@ -61,13 +62,11 @@ def test_split_config4_mm_with_50k_path_bag(split_mode):
     compare(run_mm_hip(m), cases.run_mm(m), "bf16x3 config4 concat", kink_units=relu_kink_units(sd, xp))
 
 
-def test_split_below_the_threshold_runs_the_exact_kernels(split_mode, monkeypatch):
-    """Bags below split_min_rows() (1,024 instances) are a dozen launch latencies: the mode leaves them on the exact-fp32 kernels."""
-    from multimodalfusion_amd._lib import KernelTrace
-    with KernelTrace() as tr:
-        run_path_hip(_case(700), monkeypatch)
-    names = set(tr.dump().keys())
-    assert not {n for n in names if "split" in n}, names
+def test_split_scores_do_not_depend_on_the_bag_size(split_mode):
+    """Every bag size takes the split tiles (split_min_rows() = 1), so the heat-map property holds in this mode too, bit
+    for bit: 512-patch batches score exactly like the concatenated bag (tests/test_gpu_infer.py)."""
+    import test_gpu_infer as I
+    I.test_patch_batches_score_like_the_whole_bag_and_percentiles_match_scipy()
 
 
 def test_split_kernels_are_the_ones_that_ran(split_mode, monkeypatch):
