@@ -823,7 +823,10 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   //   D  256 short tiles         -> slot 2's last, so that both slots end at R T
   //   E  the remaining rows as short tiles (twice as many CUs work on them, each for half the time)
   // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
-  static const int env_mixed = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : 1;   // A/B switch
+  // split-operand tiles: their main loop is short against their epilogue, and the out-of-phase plan's extra short tiles
+  // cost more than the phase offset wins (A + E only: 91.2 us; dephased: 96.4; uniform tiles: 94.5)
+  static const int env_gate = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : -1;   // A/B switch
+  const int env_mixed = env_gate >= 0 ? env_gate : (split ? 2 : 1);
   int64_t mt = (p.N + 127) / 128;
   const int64_t slots = 512, total = mt * p.nt_count;
   const int R = (int)(total / slots);
