@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=0,
                     help="bags in flight per GPU: steps are issued round-robin on this many HIP streams, each with its "
                          "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time; "
-                         "0 = default: 3 (fp32), 2 (bf16: its 0.4 ms steps become host-bound beyond two)")
+                         "0 = default: 3 (fp32), 2 (bf16: its 0.4 ms steps become host-bound beyond two; --gemm bf16x3: power-limited)")
     ap.add_argument("--autograd", action="store_true",
                     help="time the step through the autograd surface (model -> loss -> backward) instead of the one-call step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -586,7 +586,7 @@ def main():
     bf16 = args.dtype == "bf16"
     if bf16:
         x = x.to(torch.bfloat16)
-    inflight = args.inflight if args.inflight > 0 else (2 if bf16 else 3)
+    inflight = args.inflight if args.inflight > 0 else (2 if bf16 or args.gemm == "bf16x3" else 3)
     if args.gemm == "bf16x3" and not bf16:
         from multimodalfusion_amd import ops
         ops.set_gemm(1)
@@ -657,7 +657,9 @@ def main():
             out["other_sizes"] = extra
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
             if not bf16 and args.gemm == "f32":
-                out["gemm_bf16x3"] = gemm_bf16x3_leg(model, x, dev, args.steps, args.warmup, inflight)
+                # two bags in flight: this mode keeps the package at its power limit by itself (1,907 bags/s with two,
+                # 1,875 with three, 1,844 with four in the same run)
+                out["gemm_bf16x3"] = gemm_bf16x3_leg(model, x, dev, args.steps, args.warmup, min(inflight, 2))
                 # the same two headline figures in that mode, at top level beside `value` (never instead of it)
                 out["value_gemm_bf16x3"] = out["gemm_bf16x3"]["value"]
                 out["ms_per_step_one_bag_gemm_bf16x3"] = out["gemm_bf16x3"]["ms_per_step_one_bag"]
