@@ -1312,13 +1312,17 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 }
 
 // > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
-static inline bool dh_short_grid(int64_t N, int H) {       // the 64x64 tiles on a grid of at most 512 workgroups
+static inline bool dh_short_grid(int64_t N, int H, int split = 0) {       // the 64x64 tiles on a grid of at most 512 workgroups
   static const int cap = getenv("MMF_DH_SHORT_MAX") ? atoi(getenv("MMF_DH_SHORT_MAX")) : 512;   // tuning override
-  return !use_wide_tiles(N, H) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= cap;
+  return !use_wide_tiles(N, H, split) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= cap;
+}
+// the split-operand mode's 64 x 64 K-dh tiles: every bag below its wide tiles
+static inline bool dh_split_small_ok(int64_t N, int H, int D, int gated, int split) {
+  return split && !use_wide_tiles(N, H, 1) && N >= split_min_rows() && ((gated ? 2 : 1) * D / SKC) % 4 == 0;
 }
 // the split-operand K-dh: the training step's shape only (fused K-prep, wide tiles)
 bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {
-  return split && use_wide_tiles(N, H) && ((gated ? 2 : 1) * D / SKC) % 4 == 0;
+  return split && use_wide_tiles(N, H, 1) && ((gated ? 2 : 1) * D / SKC) % 4 == 0;
 }
 int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
 
@@ -1326,8 +1330,9 @@ int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int 
   static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
-  if (dh_short_grid(N, H)) return (int)((N + 63) / 64);
-  if (!use_wide_tiles(N, H)) return 0;
+  const int sm = dh_split_small_ok(N, H, D, gated, split);
+  if (dh_short_grid(N, H, sm)) return (int)((N + 63) / 64);
+  if (sm || !use_wide_tiles(N, H, split)) return 0;
   if (bwd_dh_split_ok(N, H, D, gated, split)) return (int)((N + bwd_dh_split_rows(N) - 1) / bwd_dh_split_rows(N));
   const int rows = pick_wide_rows(N, H / 256, allow_half != 0);   // the fused launch always has the forward's relu bits
   return (int)((N + rows - 1) / rows);
@@ -1374,10 +1379,9 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (p.g.D % KC != 0 || p.H % 4 != 0) return MMF_ERR_SHAPE;
   if (p.N <= 0) return MMF_OK;
   if (p.fused_prep && bwd_dh_split_ok(p.N, p.H, p.g.D, p.g.gated, p.split)) return launch_bwd_dh_split<224>(p, st);
-  if (p.split && !use_wide_tiles(p.N, p.H) && (p.N / 128) * ((p.H + 127) / 128) < 256 && p.N >= split_min_rows() &&
-      ((p.g.gated ? 2 : 1) * p.g.D / SKC) % 4 == 0 && (!p.fused_prep || dh_short_grid(p.N, p.H)))
+  if (dh_split_small_ok(p.N, p.H, p.g.D, p.g.gated, p.split) && (!p.fused_prep || dh_short_grid(p.N, p.H, 1)))
     return launch_bwd_dh_split_small(p, st);
-  if (use_wide_tiles(p.N, p.H)) {
+  if (use_wide_tiles(p.N, p.H, p.split)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
       case 64: return launch_bwd_dh_wide<64>(p, st);

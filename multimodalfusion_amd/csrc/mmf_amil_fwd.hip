@@ -718,9 +718,12 @@ int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
   }
   return best;
 }
-bool use_wide_tiles(int64_t M, int N) {
+bool use_wide_tiles(int64_t M, int N, int split) {
   static const int env = getenv("MMF_WIDE") ? atoi(getenv("MMF_WIDE")) : 1;
-  static const int min_rows = getenv("MMF_WIDE_MIN") ? atoi(getenv("MMF_WIDE_MIN")) : 64 * 256;   // tuning override
+  static const int min_env = getenv("MMF_WIDE_MIN") ? atoi(getenv("MMF_WIDE_MIN")) : 0;   // tuning override
+  // crossover against the 64-row tiles, one bag per step: exact fp32 16,384 rows (0.300 vs 0.329 ms there); the
+  // split-operand tiles cross later -- 16,384: 0.307 wide vs 0.284 small, 24,000: 0.355 vs 0.412
+  const int min_rows = min_env > 0 ? min_env : (split ? 80 * 256 : 64 * 256);
   return env && N % 256 == 0 && M * (int64_t)(N / 256) >= min_rows;
 }
 
@@ -751,7 +754,8 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
   if (p.M <= 0) return MMF_OK;
-  if (p.split && use_wide_tiles(p.M, p.N) && p.K % (4 * SKC) == 0 && p.nseg == 1) {
+  const bool can_split = p.split && p.K % (4 * SKC) == 0 && p.nseg == 1;
+  if (can_split && use_wide_tiles(p.M, p.N, 1)) {
     static const int rows = getenv("MMF_SPLIT_ROWS") ? atoi(getenv("MMF_SPLIT_ROWS")) : 224;
     static const int gm = getenv("MMF_SPLIT_GM") ? atoi(getenv("MMF_SPLIT_GM")) : 1;      // A/B switch
     if (gm == 2 && rows == 224) return launch_linear_split<224, 1, 8, 2>(p, st);
@@ -759,7 +763,7 @@ int launch_linear(LinearParams p, hipStream_t st) {
     if (rows == 192) return launch_linear_split<192, 1, 8>(p, st);
     return launch_linear_split<224, 1, 8>(p, st);
   }
-  if (use_wide_tiles(p.M, p.N)) {
+  if (use_wide_tiles(p.M, p.N, can_split)) {
     switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0)) {
       case 64: return launch_linear_wide<64>(p, st);
       case 128: return launch_linear_wide<128>(p, st);
@@ -768,12 +772,12 @@ int launch_linear(LinearParams p, hipStream_t st) {
       default: return launch_linear_wide<224>(p, st);
     }
   }
-  if (use_big_tiles(p.M, p.N)) {
+  if (!can_split && use_big_tiles(p.M, p.N)) {
     p.mt_count = (int)((p.M + 127) / 128); p.nt_count = (p.N + 127) / 128;
     return launch_tiled<TileNT128>("linear_nt_kernel", linear_nt_kernel<TileNT128>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
   p.mt_count = (int)((p.M + 63) / 64); p.nt_count = (p.N + 63) / 64;
-  if (p.split && p.nseg == 1 && p.K % (4 * SKC) == 0 && p.M >= split_min_rows()) {
+  if (can_split && p.M >= split_min_rows()) {
     using T = TileSp<64, 64, 2, 2>;
     return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }

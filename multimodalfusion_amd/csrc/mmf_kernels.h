@@ -233,7 +233,7 @@ int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int 
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
 int pick_wide_rows(int64_t M, int ntn, bool allow_half);
-bool use_wide_tiles(int64_t M, int N);
+bool use_wide_tiles(int64_t M, int N, int split = 0);   // split: the bf16x3 mode's (later) crossover
 // split-K plan shared by the workspace carving and the launcher
 int tn_tile_dim(int64_t K, int D_gate);                    // 256: one 8-wave 256x256 workgroup per CU; else 128
 int tn_splits(int64_t K, int total_tiles, int tile);
