@@ -1428,7 +1428,8 @@ int launch_nn(NnParams p, hipStream_t st) {
 // splits (slab traffic) for the same number of workgroups, so it is used only for long K.
 int tn_tile_dim(int64_t K, int D_gate) {
   static const int env = getenv("MMF_TN_WIDE") ? atoi(getenv("MMF_TN_WIDE")) : 1;
-  if (!env || K < 12288) return 128;      // measured crossover: 10k bags 236 vs 243 us per step, 14k 294 vs 289
+  static const int kmin = getenv("MMF_TN_WIDE_MIN") ? atoi(getenv("MMF_TN_WIDE_MIN")) : 12288;   // tuning override
+  if (!env || K < kmin) return 128;       // measured crossover: 10k bags 236 vs 243 us per step, 14k 294 vs 289
   (void)D_gate;
   return 256;
 }
