@@ -346,6 +346,7 @@ def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
     N = x.shape[0]
     prev = ops.set_gemm(1)
     try:
+        steps = max(steps, 100)
         one = make_step(model, x, dev, None, 1)
         d1 = time_steps(one, steps, warmup, 1)
         prof = kernel_profile(one, max(5, min(steps, 20)))
@@ -356,8 +357,8 @@ def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
             g.manual_seed(4321)
             for n2 in (1000, 10000):
                 x2 = torch.randn(n2, 1024, device=dev, generator=g)
-                d2 = time_steps(make_step(model, x2, dev, None, 1), max(steps, 100), warmup, 1)
-                sizes[str(n2)] = {"ms_per_step": 1e3 * d2 / max(steps, 100), "bags_per_s": max(steps, 100) / d2}
+                d2 = time_steps(make_step(model, x2, dev, None, 1), max(steps, 200), warmup, 1)
+                sizes[str(n2)] = {"ms_per_step": 1e3 * d2 / max(steps, 200), "bags_per_s": max(steps, 200) / d2}
     finally:
         ops.set_gemm(prev)
         for p in model.parameters():
@@ -645,14 +646,15 @@ def main():
         if args.extras and world == 1:
             # north_star's other bag sizes: eager (host-bound: Python + autograd + ~12 launches) and as one hipGraph
             extra = {}
+            k2 = max(args.steps, 200)           # 0.1-0.25 ms steps: a short run would mostly measure the clock ramp
             for n2 in (1000, 10000):
                 x2 = torch.randn(n2, 1024, device=dev, generator=g)
-                d2 = time_steps(make_step(model, x2, dev, None, 1), args.steps, args.warmup, 1)
-                ms2 = 1e3 * d2 / args.steps
+                d2 = time_steps(make_step(model, x2, dev, None, 1), k2, args.warmup, 1)
+                ms2 = 1e3 * d2 / k2
                 d3 = time_steps(make_step(model, x2, dev, None, 1, True), args.steps, args.warmup, 1)
                 for p in model.parameters():
                     p.grad = None
-                extra[str(n2)] = {"bags_per_s": args.steps / d2, "ms_per_step": ms2, **size_fractions(n2, ms2),
+                extra[str(n2)] = {"bags_per_s": k2 / d2, "ms_per_step": ms2, **size_fractions(n2, ms2),
                                   "autograd_surface_ms_per_step": 1e3 * d3 / args.steps}
             out["other_sizes"] = extra
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
