@@ -70,7 +70,13 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   if (e >= s.rows * s.cols) return;
   const int r = e / s.cols, c = e - r * s.cols;
   const bf16_t v = f2bf(s.src[e]);
-  if (s.transpose == 2) s.dst[(size_t)c * s.dst_ld + s.c0 + (r >> 5) * 64 + (r & 31)] = v;   // 32-row blocks, 64 apart
+  if (s.transpose == 3) {
+    const int kt = c >> 6, q = (c >> 4) & 3, hh = (c >> 3) & 1, w = r >> 6, fb = (r >> 5) & 1;
+    s.dst[((size_t)((((kt * 4 + w) * 4 + q) * 2 + fb) * 64 + hh * 32 + (r & 31))) * 8 + (c & 7)] = v;
+  } else if (s.transpose == 4) {
+    const int ps = r >> 6, w = (r >> 4) & 3, sk = c >> 4, hh = (c >> 3) & 1;
+    s.dst[((size_t)(((ps * 4 + w) * 16 + sk) * 64 + hh * 32 + s.c0 + (r & 15))) * 8 + (c & 7)] = v;
+  } else if (s.transpose == 2) s.dst[(size_t)c * s.dst_ld + s.c0 + (r >> 5) * 64 + (r & 31)] = v;   // 32-row blocks, 64 apart
   else if (s.transpose) s.dst[(size_t)c * s.dst_ld + s.c0 + r] = v;
   else s.dst[(size_t)r * s.dst_ld + s.c0 + c] = v;
 }

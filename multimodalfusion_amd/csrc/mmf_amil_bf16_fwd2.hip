@@ -1,0 +1,361 @@
+// K-fwd, second form (bf16 storage, H = D = 256, gated): instance projection + gated attention scoring + pooling
+// partials of one 128-instance tile, built so that TWO workgroups share a CU (4 waves, <= 256 VGPRs, < 80 KB of LDS
+// each).  The first form (mmf_amil_bf16.hip) runs one 8-wave workgroup per CU and its phases -- operand stream,
+// MFMA, VALU-bound epilogues, gate phase, pooling -- strictly one after the other: the CU's load path idles for two
+// thirds of a tile's life (profiles/r02: 0.26 of the HBM rate).  With two independent workgroups per CU the
+// hardware overlaps one tile's epilogues / gate phase with the other's operand stream and MFMAs.
+//
+// What makes the halved budget fit:
+//   * TRANSPOSED products.  Both GEMMs are computed as (weights) x (instances)^T: the MFMA's A operand is a block of
+//     32 weight rows, its B operand 32 instances.  In the 32x32 accumulator a lane then holds ONE instance and groups
+//     of 4 consecutive output features -- the contiguous direction of every output ([instance][feature] rows of h,
+//     a, b) -- so the epilogues pack 4 values to 8 bytes and write them where they belong: no fp32 transpose through
+//     LDS (37 KB of scratch and ~1/3 of the old epilogues' instructions), and the biases sit in the accumulators'
+//     initial value instead of the epilogue.
+//   * WEIGHTS NEVER TOUCH LDS.  The per-call bf16 copies of W1 and [Wa ; Wb] are written in MFMA-fragment order
+//     (cvt_bf16_kernel, CvtSeg::transpose 3 / 4): one buffer_load_dwordx4 per lane IS an A fragment, a wave
+//     instruction reads 1 KB of contiguous memory, and each of the 4 waves loads only the rows it multiplies
+//     (wave w owns hidden features 64 w .. 64 w + 63; in the gate phase attention dims 64 p + 16 w .. + 15 of pass
+//     p = 0..3).  LDS holds only the x chunks (three 16 KB stages, LDS-DMA) and then the tile's h image (64 KB,
+//     aliasing the stages).
+//   * the gate weights of a pass (32 rows = 16 tanh + 16 sigmoid rows of the same dims, K = 256: 64 VGPRs) are
+//     refilled k-step by k-step for the next pass right behind the MFMA that used them.
+//
+// LDS map (bytes): [0, 49152) three x stages of [128 rows][128 B] (XOR-swizzled as mmf_gemm_dma.h), later
+//                  [0, 65536) h image [128 rows][512 B], 16-byte slots XOR-swizzled with (row & 15);
+//                  [65536, ...) score partials [4 waves][128], e[128], scratch[16], pooling partials [8][256].
+// Reference lines: models/model_attention_mil_path.py:52-56 (projection, attention net, softmax pooling),
+// models/model_modules.py:105-110 (Attn_Net_Gated.forward).
+#include <type_traits>
+#include <cstdlib>
+
+#include "mmf_gemm_dma.h"
+#include "mmf_bf16.h"
+
+namespace mmf {
+
+constexpr int F2_BM = 128;
+constexpr int F2_STAGE = F2_BM * 128;                 // one x chunk: 128 rows x 64 bf16
+constexpr int F2_HIMG = 0, F2_MISC = 65536;
+constexpr int F2_LDS_BYTES = F2_MISC + (4 * 128 + 128 + 16 + 8 * 256) * 4;
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// A-fragment load hidden from the compiler's wait bookkeeping (the x stream's LDS-DMAs share the in-order VM
+// counter; completion is counted by hand in the main loop, cdna_hip_programming.md "mixing load KINDS in one k-loop")
+template <int IMM>
+__device__ inline void ldw_asm(f32x4v& dst, const DmaRsrc& rs, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=&v"(dst) : "v"(voff), "s"(rs.w), "s"(soff), "n"(IMM) : "memory");
+}
+__device__ inline void bst4(rsrc_t r, unsigned voff, const float4& v) {
+  u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)voff, 0, 0);
+}
+__device__ inline bf16x8 frag_of(const f32x4v& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ inline bf16x8 frag_of(const float4& v) {
+  f32x4v t = {v.x, v.y, v.z, v.w};
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+// MFMAs of one staged x chunk (64 k) against the wave's 64 weight rows held in `wf` (k-step q, row block fb -> wf[2q + fb])
+__device__ inline void f2_chunk(const char* xs, const f32x4v (&wf)[8], f32x16 (&acc)[2][4], int r, int hh) {
+  const int sw = (r >> 1) & 7;
+  const char* b0 = xs + r * 128;
+  float4 fx[2][4];
+  auto rd = [&](int q, int buf) {
+    const int o = 16 * ((2 * q + hh) ^ sw);
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) fx[buf][ib] = *reinterpret_cast<const float4*>(b0 + ib * 32 * 128 + o);
+  };
+  rd(0, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q + 1 < 4) rd(q + 1, (q + 1) & 1);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+        acc[fb][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(wf[2 * q + fb]), frag_of(fx[q & 1][ib]), acc[fb][ib], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdParams p) {
+  extern __shared__ __align__(16) char lds2[];
+  char* lds = lds2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int mt = blockIdx.x, row0 = mt * F2_BM;
+  const uint32_t sdev = p.seed_dev ? *p.seed_dev : 0u;
+  float* sred = reinterpret_cast<float*>(lds + F2_MISC);         // [4 waves][128 rows]
+  float* e_l = sred + 4 * 128;                                    // [128]
+  float* red = e_l + 128;                                         // [16]
+  float* vred = red + 16;                                         // [8][256]
+
+  // ---------------- phase 1: u^T = W1 . x^T (K = L) ------------------------------------------------------------
+  f32x16 acc[2][4];                                               // [feature block fb][instance block ib]
+#pragma unroll
+  for (int fb = 0; fb < 2; ++fb) {
+    float bias[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t = ld4(p.b1 + 64 * wave + 32 * fb + 8 * g + 4 * hh);
+      bias[4 * g] = t.x; bias[4 * g + 1] = t.y; bias[4 * g + 2] = t.z; bias[4 * g + 3] = t.w;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[fb][ib][i] = bias[i];
+    asm volatile("" :: "v"(bias[0]), "v"(bias[4]), "v"(bias[8]), "v"(bias[12]));   // the compiler's own waits for these loads stay in front of the hidden queue
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the hand-counted queue below starts empty
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    DmaK<F2_BM, 256> lx;
+    lx.init(p.x, p.L, row0, (int)p.N);
+    DmaRsrc rw;
+    rw.set(p.w1f, 256u * (unsigned)p.L * 2u);
+    const unsigned vw0 = (unsigned)lane * 16u + (unsigned)wave * 8192u, vw1 = vw0 + 4096u;
+    f32x4v wf0[8], wf1[8];
+    auto load_w = [&](int kt, f32x4v (&w)[8]) {
+      const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)kt * 32768u);
+      ldw_asm<0>(w[0], rw, vw0, so); ldw_asm<1024>(w[1], rw, vw0, so); ldw_asm<2048>(w[2], rw, vw0, so); ldw_asm<3072>(w[3], rw, vw0, so);
+      ldw_asm<0>(w[4], rw, vw1, so); ldw_asm<1024>(w[5], rw, vw1, so); ldw_asm<2048>(w[6], rw, vw1, so); ldw_asm<3072>(w[7], rw, vw1, so);
+    };
+    auto stage = [&](int kt) { return lds + (kt % 3) * F2_STAGE; };
+    const int nk = p.L / 64;                                      // even (launcher)
+    // queue order per iteration: [W(kt+1) x 8] [x(kt+2) x 4]; before chunk kt+1 is read everything up to W(kt+1) has
+    // landed (vmcnt(4)), x(kt+2) may still be in flight
+    load_w(0, wf0);
+    lx.issue(0, stage(0));
+    if (nk > 1) lx.issue(1, stage(1));
+    if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
+      if (kt + 1 < nk) load_w(kt + 1, wnext);
+      if (kt + 2 < nk) lx.issue(kt + 2, stage(kt + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      f2_chunk(stage(kt), wcur, acc, r, hh);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      iter(kt, wf0, wf1);
+      iter(kt + 1, wf1, wf0);
+    }
+  }
+
+  // ---------------- epilogue 1: h = bf16(drop(relu(u))) -> the LDS h image (B operand of phase 2, pooled operand) ----
+  {
+    const uint32_t thr = drop_threshold(p.p_h);
+    const float scale = p.p_h > 0.f ? 1.0f / (1.0f - p.p_h) : 1.0f;
+    const uint32_t dkey = p.key_h + sdev;
+    auto epi = [&](auto drop_c) {
+      constexpr bool DROP = decltype(drop_c)::value;
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+          const int R = 32 * ib + r;
+          char* rowp = lds + F2_HIMG + R * 512 + 8 * hh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int f = 64 * wave + 32 * fb + 8 * g + 4 * hh;
+            float y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              y[j] = fmaxf(acc[fb][ib][4 * g + j], 0.f);
+              if constexpr (DROP) y[j] = keep(dkey, (uint32_t)(row0 + R) * 256u + (uint32_t)(f + j), thr) ? y[j] * scale : 0.f;
+            }
+            const int slot = 8 * wave + 4 * fb + g;
+            *reinterpret_cast<uint2*>(rowp + 16 * (slot ^ (R & 15))) = pack4(y[0], y[1], y[2], y[3]);
+          }
+        }
+    };
+    if (p.p_h > 0.f) epi(std::true_type{}); else epi(std::false_type{});
+  }
+  // the wave's gate weights of pass 0 (16 k-steps x one 32-row A block): in flight across the barrier and the h copy
+  const rsrc_t rg = make_rsrc(p.wabf, 512u * 256u * 2u);
+  const unsigned vg = (unsigned)lane * 16u + (unsigned)wave * 16384u;
+  float4 wg[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wg[s] = bld4(rg, vg, (unsigned)s * 1024u);
+  __syncthreads();                                         // h tile complete
+  // saved activations go out through buffer stores: rows beyond the bag fall outside num_records and are dropped
+  const unsigned act_bytes = (unsigned)p.N * 512u;
+  if (p.h) {                                               // whole 512-byte rows per wave instruction
+    const rsrc_t rh = make_rsrc(p.h, act_bytes);
+    const int s = tid & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int R = 8 * i + (tid >> 5);
+      const float4 v = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (s ^ (R & 15)));
+      bst4(rh, (unsigned)(row0 + R) * 512u + 16u * (unsigned)s, v);
+    }
+  }
+  const rsrc_t rsa = make_rsrc(p.a ? p.a : p.h, p.a ? act_bytes : 0u), rsb = make_rsrc(p.a ? p.b : p.h, p.a ? act_bytes : 0u);
+
+  // ---------------- phase 2: [a ; b]^T of 16 dims per pass = (32 weight rows) . h^T, four passes -----------------------
+  const uint32_t thr_a = drop_threshold(p.p_att);
+  const bool drop = p.p_att > 0.f;
+  const float dscale = drop ? 1.0f / (1.0f - p.p_att) : 1.0f;
+  const uint32_t key_a = p.key_a + sdev, key_b = p.key_b + sdev;
+  float sc[4] = {0.f, 0.f, 0.f, 0.f};                      // score partials of instance 32 ib + r over this lane's dims
+  const char* hb0 = lds + F2_HIMG + r * 512;
+  const int sx = r & 15;
+#pragma unroll 1
+  for (int ps = 0; ps < 4; ++ps) {
+    const int dbase = 64 * ps + 16 * wave;
+    const unsigned next_w = __builtin_amdgcn_readfirstlane((unsigned)(ps + 1) * 65536u);   // pass 4 does not exist: reads as zero
+    asm volatile("" ::: "memory");                         // the h fragments are re-read every pass (hoisted out of the loop they spill)
+    f32x16 ag[4];
+    float wc[8];
+    {
+      // rows 0-15 of the A block are Wa (dims dbase ..), rows 16-31 Wb: accumulator i < 8 is pre-tanh, i >= 8 pre-sigmoid
+      // of dim dbase + 8 ((i >> 2) & 1) + 4 hh + (i & 3)
+      float bias[16];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 ta = ld4(p.ba + dbase + 8 * g + 4 * hh), tb = ld4(p.bb + dbase + 8 * g + 4 * hh), tw = ld4(p.Wc + dbase + 8 * g + 4 * hh);
+        bias[4 * g] = ta.x; bias[4 * g + 1] = ta.y; bias[4 * g + 2] = ta.z; bias[4 * g + 3] = ta.w;
+        bias[8 + 4 * g] = tb.x; bias[8 + 4 * g + 1] = tb.y; bias[8 + 4 * g + 2] = tb.z; bias[8 + 4 * g + 3] = tb.w;
+        wc[4 * g] = tw.x; wc[4 * g + 1] = tw.y; wc[4 * g + 2] = tw.z; wc[4 * g + 3] = tw.w;
+      }
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ag[ib][i] = bias[i];
+    }
+    float4 fh[2][4];
+    auto rdh = [&](int s, int buf) {
+      const int o = 16 * ((2 * s + hh) ^ sx);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) fh[buf][ib] = *reinterpret_cast<const float4*>(hb0 + ib * 32 * 512 + o);
+    };
+    rdh(0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) rdh(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+        ag[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(wg[s]), frag_of(fh[s & 1][ib]), ag[ib], 0, 0, 0);
+      wg[s] = bld4(rg, vg, next_w + (unsigned)(s * 1024));   // next pass's weights of this k-step
+    }
+    // ---- activations, a / b stores (16 contiguous bytes per lane after the half swap), score partials ----
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const int R = 32 * ib + r, row = row0 + R;
+      uint32_t pa[4], pb[4];                               // [2 g + (0: dims 0-1, 1: dims 2-3 of the group)]
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = fast_tanh(ag[ib][4 * g + j]);
+          bv[j] = fast_sigmoid(ag[ib][8 + 4 * g + j]);
+        }
+        pa[2 * g] = pack2(av[0], av[1]); pa[2 * g + 1] = pack2(av[2], av[3]);
+        pb[2 * g] = pack2(bv[0], bv[1]); pb[2 * g + 1] = pack2(bv[2], bv[3]);
+        // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
+        unpack2(pa[2 * g], av[0], av[1]); unpack2(pa[2 * g + 1], av[2], av[3]);
+        unpack2(pb[2 * g], bv[0], bv[1]); unpack2(pb[2 * g + 1], bv[2], bv[3]);
+        const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(dbase + 8 * g + 4 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float ad = av[j], bd = bv[j];
+          if (drop) {
+            ad = keep(key_a, idx + j, thr_a) ? ad * dscale : 0.f;
+            bd = keep(key_b, idx + j, thr_a) ? bd * dscale : 0.f;
+          }
+          sc[ib] += ad * bd * wc[4 * g + j];
+        }
+      }
+      if (p.a) {
+        // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
+        // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
+        uint32_t oa[4], ob[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          auto sa = __builtin_amdgcn_permlane32_swap(pa[q], pa[2 + q], false, false);
+          auto sb = __builtin_amdgcn_permlane32_swap(pb[q], pb[2 + q], false, false);
+          oa[q] = sa[0]; oa[2 + q] = sa[1];
+          ob[q] = sb[0]; ob[2 + q] = sb[1];
+        }
+        const unsigned o = (unsigned)row * 512u + (unsigned)(dbase + 8 * hh) * 2u;
+        bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
+        bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
+      }
+    }
+  }
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib) {
+    const float s = sc[ib] + __shfl_xor(sc[ib], 32, 64);
+    if (hh == 0) sred[wave * 128 + 32 * ib + r] = s;
+  }
+  __syncthreads();
+
+  // ---------------- scores of the tile, online-softmax partial, pooling partial ----------------------------------------
+  const float bc = p.bc[0];
+  float sv = -INFINITY;
+  if (tid < 128) {
+    const int row = row0 + tid;
+    const float s = bc + sred[tid] + sred[128 + tid] + sred[256 + tid] + sred[384 + tid];
+    if (row < p.N) { p.A_raw[row] = s; sv = s; }
+  }
+  float m = wave_max(sv);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(red[0], red[1]);                               // the rows live in threads 0..127 = waves 0, 1
+  const float ev = sv > -INFINITY ? __expf(sv - m) : 0.f;
+  if (tid < 128) e_l[tid] = ev;
+  const float lsum = wave_sum(ev);
+  if (lane == 0) red[8 + wave] = lsum;
+  __syncthreads();
+  {
+    const int fg = tid & 31, ig = tid >> 5;                // 8 features x 16 instances per thread
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int R = 16 * ig + i;
+      const float4 raw = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (fg ^ (R & 15)));
+      float hv[8];
+      unpack8(raw, hv);
+      const float e = e_l[R];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += e * hv[k];
+    }
+    float* o = vred + ig * 256 + 8 * fg;
+    st4(o, make_float4(v[0], v[1], v[2], v[3]));
+    st4(o + 4, make_float4(v[4], v[5], v[6], v[7]));
+  }
+  __syncthreads();
+  float* out = p.partials + (size_t)mt * (2 + 256);
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += vred[q * 256 + tid];
+    out[2 + tid] = s;
+  }
+  if (tid == 0) { out[0] = m; out[1] = red[8] + red[9]; }
+}
+
+bool fused_fwd2_ok(int64_t N, int L, int H, int D) {
+  static const int env = getenv("MMF_BF16_FUSED") ? atoi(getenv("MMF_BF16_FUSED")) : 2;   // A/B switch: 1 = first form, 0 = unfused kernels
+  return env == 2 && H == 256 && D == 256 && L % 128 == 0 && fused_fwd_tiles(N) <= 4096;
+}
+
+int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st) {
+  if (!gated || p.D != 256 || p.L % 128 != 0 || !p.w1f || !p.wabf) return MMF_ERR_SHAPE;
+  p.mt_count = fused_fwd_tiles(p.N);
+  auto kern = amil_fwd_fused2_bf16_kernel;
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), F2_LDS_BYTES)) return e;
+  ProfScope ps("amil_fwd_fused_bf16_kernel", st);
+  hipLaunchKernelGGL(kern, dim3(p.mt_count), dim3(256), F2_LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
+}  // namespace mmf

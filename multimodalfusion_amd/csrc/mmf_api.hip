@@ -437,19 +437,23 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   auto cvt = [&](const float* src, bf16_t* dst, int rows, int cols, int dst_ld, int c0, int transpose) {
     cp.seg[cp.nseg++] = CvtSeg{src, dst, rows, cols, dst_ld, c0, transpose, 0};
   };
-  cvt(d->W1, w.w1, d->H, d->L, d->L, 0, 0);
-  cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, 0);
+  // the fused forward's second form reads W1 / [Wa ; Wb] in MFMA-fragment order (same bytes, same workspace slots)
+  const bool fused2 = d->gated && fused_fwd2_ok(d->N, d->L, d->H, d->D);
+  cvt(d->W1, w.w1, d->H, d->L, d->L, 0, fused2 ? 3 : 0);
+  cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, fused2 ? 4 : 0);
   if (!infer) cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, d->gated ? 2 : 1);     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
   if (d->gated) {
-    cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
+    if (fused2) cvt(d->Wb, w.wab, d->D, d->H, d->H, 16, 4);
+    else cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
     if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
   }
   if (int e = launch_cvt_bf16(cp, st)) return e;
 
-  if (d->gated && d->D == 256 && fused_fwd_ok(d->N, d->L, d->H, d->D)) {   // `small` gated stack: one kernel for projection + scoring + pooling partials
+  if (fused2 || (d->gated && d->D == 256 && fused_fwd_ok(d->N, d->L, d->H, d->D))) {   // `small` gated stack: one kernel for projection + scoring + pooling partials
     FusedFwdParams fp{};
     fp.x = x; fp.w1 = w.w1; fp.b1 = d->b1;
     fp.Wa = w.wab; fp.Wb = d->gated ? w.wab + (size_t)d->D * d->H : nullptr;
+    fp.w1f = w.w1; fp.wabf = w.wab;
     fp.ba = d->ba; fp.bb = d->bb; fp.Wc = d->Wc; fp.bc = d->bc;
     fp.h = infer ? nullptr : w.h; fp.a = w.a; fp.b = w.b;       // a / b are null when carved for inference
     fp.A_raw = A_raw; fp.partials = w.partials;
@@ -457,6 +461,9 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     fp.p_h = d->p_h; fp.p_att = d->p_att;
     fp.key_h = drop_key(d->seed, 0); fp.key_a = drop_key(d->seed, 1); fp.key_b = drop_key(d->seed, 2);
     fp.seed_dev = seed_dev;
+    if (fused2) {
+      if (int e = launch_fused_fwd2_bf16(fp, d->gated, st)) return e;
+    } else
     if (int e = launch_fused_fwd_bf16(fp, d->gated, st)) return e;
     // (Tried: sending the rows of a sparse last round -- 782 tiles at 100k = 3 rounds of 256 + 14 -- through the three
     // unfused kernels instead.  The fused kernel drops 173 -> 141 us, but the three small launches cost 48 us.)

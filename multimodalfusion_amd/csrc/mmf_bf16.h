@@ -38,6 +38,10 @@ __device__ inline uint2 pack4(float a, float b, float c, float d) { return make_
 
 struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  transpose 1: dst[c][c0 + r];
                            // transpose 2: dst[c][c0 + 64 (r / 32) + r % 32]  (K-dh's interleaved [Wa-block | Wb-block] k order)
+                           // transpose 3: W1 [256 x L] in the fused forward's A-fragment order: 16-byte unit (8 k) of
+                           //   lane 32 hh + i, k-step q, row block fb, wave w, chunk kt at ((((kt 4 + w) 4 + q) 2 + fb) 64 + lane)
+                           // transpose 4: Wa (c0 = 0) / Wb (c0 = 16) [256 x 256], unit of lane 32 hh + c0 + (d & 15), k-step s,
+                           //   wave w = (d >> 4) & 3, pass ps = d >> 6 at (((ps 4 + w) 16 + s) 64 + lane)
   const float* src; bf16_t* dst;
   int rows, cols, dst_ld, c0, transpose, block_begin;
 };
@@ -106,6 +110,7 @@ int launch_pool_partial_bf16(PoolBfParams& p, hipStream_t st);   // partials onl
 struct FusedFwdParams {     // fused forward (H = 256): instance projection + gate scoring + pooling partials
   const bf16_t* x; const bf16_t* w1; const float* b1;
   const bf16_t *Wa, *Wb; const float *ba, *bb, *Wc, *bc;
+  const bf16_t *w1f, *wabf;     // second form only: W1 and [Wa ; Wb] in MFMA-fragment order (CvtSeg::transpose 3 / 4)
   bf16_t *h, *a, *b;            // saved for backward; all three null in forward-only calls
   float* A_raw; float* partials;   // partials: [fused_fwd_tiles(N)][2 + 256] = (max, sum e, sum e.h) per 128-row tile
   int64_t N; int L, D;
@@ -115,6 +120,8 @@ struct FusedFwdParams {     // fused forward (H = 256): instance projection + ga
 int fused_fwd_tiles(int64_t N);
 bool fused_fwd_ok(int64_t N, int L, int H, int D);
 int launch_fused_fwd_bf16(FusedFwdParams p, int gated, hipStream_t st);
+bool fused_fwd2_ok(int64_t N, int L, int H, int D);   // second form (mmf_amil_bf16_fwd2.hip): two 4-wave workgroups per CU
+int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st);
 int dh_bf16_row_tiles(int64_t N);              // capacity of dbc_part (upper bound over tile choices)
 int dh_bf16_tiles_used(int64_t N, int ntn);     // dbc partials launch_dh_bf16 writes for this shape
 int launch_dh_bf16(DhBfParams p, hipStream_t st);
