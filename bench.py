@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)     # a run pays ~1 ms once (clocks ramp up after the sync): keep it < 2 %
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blocks", type=int, default=12,
+                    help="the --steps block is timed this many times (each bracketed by barrier + synchronize); `value` is the "
+                         "median block's rate, min / max are reported beside it (>= 10 keeps the timed region above 150 ms at --steps 20)")
     ap.add_argument("--bag", type=int, default=50000, help="instances per bag (BASELINE metric: 50000)")
     ap.add_argument("--eval-mode", action="store_true", help="no dropout (secondary figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,30 +178,45 @@ def make_step_inflight(model, x, dev, world, n_streams, autograd=False):
     return step
 
 
-def time_steps(step, steps, warmup, world):
+def time_blocks(step, steps, warmup, world, blocks):
+    """`warmup` untimed steps, then `blocks` timed blocks of EXACTLY `steps` steps each; every block is bracketed by a
+    barrier + torch.cuda.synchronize() on both sides and its time is the MAX over ranks.  Returns the list of block times
+    (seconds).  Why blocks: one block of the default 20-100 steps is 15-75 ms of GPU time, short enough for the clock ramp
+    after an idle period and for one host hiccup to move the figure by several percent; the median over >= 10 blocks does
+    not move, and min / max are reported beside it."""
     import torch
     import torch.distributed as dist
-    # untimed: bring the device to its steady clocks first (after an idle period the first ~1 ms of work runs at
-    # ramping clocks, which is 4 % of a 30-step run), then the W warm-up steps the caller asked for
-    for _ in range(40):          # a fixed count: with N > 1 every step holds a collective, all ranks must issue the same number
-        step()
     for _ in range(warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    out = []
+    for _ in range(blocks):          # a fixed count: with N > 1 every step holds a collective, all ranks issue the same number
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def time_steps(step, steps, warmup, world, blocks=5):
+    """Median block time (seconds per `steps` steps) of `blocks` blocks: the figure the secondary legs quote."""
+    return median(time_blocks(step, steps, warmup, world, blocks))
 
 
 def step_percentiles(step, steps):
@@ -496,12 +514,13 @@ def h2d_leg(model, N, dev, steps, warmup, bf16=False):
     return res
 
 
-def cpu_baseline(N, n_bags):
-    """The oracle's torch-CPU port (kind 'port'), same op sequence as the reference's CPU path, train mode
-    with the one always-on Dropout(0.25), fp32, all host cores.  Bounded sample: `n_bags` bags after 2 warm-up."""
-    import numpy as np
+def cpu_baseline(N, n_bags, threads=None):
+    """The oracle's torch-CPU port (kind 'port'), same op sequence as the reference's CPU path
+    (models/model_attention_mil_path.py:50-72 + utils/loss_utils.py:22-39), train mode with the one always-on
+    Dropout(0.25), fp32.  The intra-op thread count is the fastest of 8/16/32/64, each candidate timed on THREE bags after
+    one warm-up bag (one timed bag per candidate picked 32 threads in one round and 8 in the next on the same CPU class);
+    pass `threads` to reuse a choice.  Bounded sample: `n_bags` bags after one more warm-up."""
     import torch
-    import torch.nn.functional as F
     from oracle import inputs as gen
     from oracle import torch_port as tp
     avail = os.cpu_count() or 1
@@ -520,33 +539,36 @@ def cpu_baseline(N, n_bags):
         loss = tp.nll_loss(hz, S, Y, c, alpha=0.0)
         loss.backward()
 
-    # the box shows every host core but a 1-GPU job owns a share of them: probe a few intra-op thread counts
-    # (1 warm + 1 timed bag each) and time the sample at the fastest, so the baseline is the CPU's best case
-    best_t, best_dt = 1, float("inf")
-    for t in sorted({min(avail, n) for n in (8, 16, 32, 64)}):
-        torch.set_num_threads(t)
-        one()
-        t0 = time.perf_counter()
-        one()
-        dt = time.perf_counter() - t0
-        if dt < best_dt:
-            best_t, best_dt = t, dt
-    torch.set_num_threads(best_t)
+    probe = {}
+    if threads is None:
+        for t in sorted({min(avail, n) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(t)
+            one()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                one()
+            probe[t] = (time.perf_counter() - t0) / 3
+        threads = min(probe, key=probe.get)
+    torch.set_num_threads(threads)
     one()
     t0 = time.perf_counter()
     for _ in range(n_bags):
         one()
     dt = time.perf_counter() - t0
-    # single-thread figure (SURVEY 8d asks for both): one timed bag
+    # single-thread figure (SURVEY 8d asks for both): one timed bag after one warm-up bag at the small sizes
     torch.set_num_threads(1)
+    if N <= 10000:
+        one()
     t0 = time.perf_counter()
     one()
     dt1 = time.perf_counter() - t0
-    torch.set_num_threads(best_t)
-    return dict(value=n_bags / dt, unit="bags/s", cores=best_t, kind="port", value_1_thread=1.0 / dt1,
+    torch.set_num_threads(threads)
+    return dict(value=n_bags / dt, unit="bags/s", cores=threads, kind="port", value_1_thread=1.0 / dt1,
+                thread_probe_s_per_bag={str(k): round(v, 4) for k, v in probe.items()},
                 sample=f"{n_bags} bags of {N}x1024 fwd+nll_surv+bwd after warm-up, fp32, train mode "
-                       f"(1 dropout mask), torch {torch.__version__} CPU, {best_t} intra-op threads "
-                       f"(fastest of 8/16/32/64 on a host showing {avail} cores); value_1_thread: one bag on one thread")
+                       f"(1 dropout mask), torch {torch.__version__} CPU, {threads} intra-op threads "
+                       f"(fastest of 8/16/32/64, three timed bags per candidate, on a host showing {avail} cores); "
+                       f"value_1_thread: one bag on one thread")
 
 
 def main():
@@ -595,7 +617,8 @@ def main():
     step = (make_step(model, x, dev, flat, world, ag) if inflight == 1
             else make_step_inflight(model, x, dev, world, inflight, ag))
 
-    dt = time_steps(step, args.steps, args.warmup, world)
+    blocks = time_blocks(step, args.steps, args.warmup, world, max(1, args.blocks))
+    dt = median(blocks)
     ms_per_step = 1e3 * dt / args.steps
     value = world * args.steps / dt
 
@@ -603,6 +626,8 @@ def main():
         "metric": "bags/sec fwd+bwd, path-AMIL 50k x 1024 synthetic bag" if N == 50000 else f"bags/sec fwd+bwd, path-AMIL {N} x 1024 synthetic bag",
         "value": value, "unit": "bags/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "blocks": {"count": len(blocks), "steps_per_block": args.steps, "timed_region_ms": 1e3 * sum(blocks),
+                   "value_median": value, "value_min": world * args.steps / max(blocks), "value_max": world * args.steps / min(blocks)},
         "dtype": args.dtype if args.gemm == "f32" or bf16 else "f32 (bf16x3 split operands on the bf16 MFMA, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"path_attention_mil small gated K=4, one {N}x1024 N(0,1) {'bf16 ' if bf16 else ''}bag per GPU per step, "
                                f"nll_surv alpha=0, {'eval' if args.eval_mode else 'train (1 dropout mask)'} mode, "
@@ -618,8 +643,10 @@ def main():
         # rank 0 only: this leg must NOT contain the collective (the other ranks are already at the final barrier)
         local_step = make_step(model, x, dev, flat, 1, ag)
         if inflight > 1 and world == 1:      # the strictly sequential figure beside it (same run)
-            d1 = time_steps(local_step, args.steps, args.warmup, 1)
-            out["one_bag_in_flight"] = {"value": args.steps / d1, "ms_per_step": 1e3 * d1 / args.steps}
+            b1 = time_blocks(local_step, args.steps, args.warmup, 1, max(1, args.blocks))
+            d1 = median(b1)
+            out["one_bag_in_flight"] = {"value": args.steps / d1, "ms_per_step": 1e3 * d1 / args.steps,
+                                        "value_min": args.steps / max(b1), "value_max": args.steps / min(b1), "blocks": len(b1)}
             # SURVEY 8(d) defines the metric as ONE bag per GPU per step: that figure at top level, beside `value`
             out["value_one_bag_per_step"] = args.steps / d1
             out["ms_per_step_one_bag"] = 1e3 * d1 / args.steps
@@ -671,8 +698,20 @@ def main():
         if args.h2d and args.extras and world == 1:
             out["pcie_inclusive"] = h2d_leg(model, N, dev, max(10, min(args.steps, 30)), args.warmup, bf16)
         if world == 1 and not args.no_cpu_baseline and not bf16:
+            # the CPU leg runs LAST (nothing on the GPU waits behind it): the metric's bag first, then north_star's other two
+            # sizes (BASELINE config 1 is the 1000 x 1024 CPU run) beside the GPU figures of `other_sizes`
             out["cpu_baseline"] = cpu_baseline(N, args.cpu_bags)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if args.extras and N == 50000:
+                small = {}
+                for n2, nb in ((10000, 20), (1000, 100)):
+                    cb = cpu_baseline(n2, nb)
+                    gpu = out.get("other_sizes", {}).get(str(n2), {}).get("bags_per_s")
+                    small[str(n2)] = {"value": cb["value"], "unit": "bags/s", "cores": cb["cores"], "kind": "port",
+                                      "value_1_thread": cb["value_1_thread"], "sample": cb["sample"],
+                                      "thread_probe_s_per_bag": cb["thread_probe_s_per_bag"],
+                                      "gpu_bags_per_s": gpu, "gpu_over_cpu": (gpu / cb["value"]) if gpu else None}
+                out["cpu_baseline_other_sizes"] = small
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

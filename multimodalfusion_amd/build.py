@@ -18,6 +18,11 @@ OBJ = os.path.join(HERE, "_build")   # objects and -save-temps output (git- and 
 SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_amil_bf16_fwd2.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
 HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_gemm_split.h", "mmf_gemm_dma.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h", "mmf_bf16.h",
            os.path.join("..", "..", "include", "mmf_amil.h")]
+# Per-file flags.  mmf_amil_bf16_fwd2.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_fma_f32 ...).  With
+# them the kernel (two 4-wave workgroups per CU, a wave's vector work beside its SIMD partner's MFMA stream) returned wrong
+# score partials in lanes 16-31 of the low register of a packed pair, a few tiles per launch, never with one workgroup per
+# CU (tools/f2_debug.py, tools/f2_debug2.py).  Packed fp32 is no gain beside MFMAs anyway (MI355X_MICROARCH.md).
+FILE_FLAGS = {"mmf_amil_bf16_fwd2.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-result"] + os.environ.get("MMF_EXTRA_FLAGS", "").split()
@@ -41,7 +46,7 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if keep_temps:
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             jobs.append(cmd)

@@ -39,11 +39,13 @@ __device__ inline unsigned long long real_now() {      // constant 100 MHz count
 #endif
 enum { BST_LIN = 0, BST_GATE = 1, BST_DH = 2, BST_TN = 3 };   // the fused forward uses BST_LIN: {projection loop, its epilogue, gate phase, pooling}
 
+void debug_stamps_fwd2(unsigned long long* out8);   // mmf_amil_bf16_fwd2.hip
 void debug_stamps_bf16(unsigned long long* out32) {
 #ifdef MMF_STAMPS
   hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_bst), 32 * sizeof(unsigned long long));
   unsigned long long z[32] = {0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_bst), z, sizeof z);
+  debug_stamps_fwd2(out32);
 #else
   for (int i = 0; i < 32; ++i) out32[i] = 0;
 #endif
@@ -62,6 +64,8 @@ static int launch_tiled_b(const char* name, void (*kern)(P), const P& p, int gri
 // =============================================================================================
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   const int b = blockIdx.x;
+  if (b == 0)
+    for (int i = threadIdx.x; i < p.nzero; i += 256) p.zero[i] = 0u;
   int si = 0;
   for (int i = 1; i < p.nseg; ++i)
     if (b >= p.seg[i].block_begin) si = i;

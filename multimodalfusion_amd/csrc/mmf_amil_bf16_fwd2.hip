@@ -23,7 +23,7 @@
 //
 // LDS map (bytes): [0, 49152) three x stages of [128 rows][128 B] (XOR-swizzled as mmf_gemm_dma.h), later
 //                  [0, 65536) h image [128 rows][512 B], 16-byte slots XOR-swizzled with (row & 15);
-//                  [65536, ...) score partials [4 waves][128], e[128], scratch[16], pooling partials [8][256].
+//                  [65536, ...) score partials [4 waves][128], e[128], scratch[16], pooling partials [8][256], ba / bb / Wc [3][256].
 // Reference lines: models/model_attention_mil_path.py:52-56 (projection, attention net, softmax pooling),
 // models/model_modules.py:105-110 (Attn_Net_Gated.forward).
 #include <type_traits>
@@ -37,9 +37,38 @@ namespace mmf {
 constexpr int F2_BM = 128;
 constexpr int F2_STAGE = F2_BM * 128;                 // one x chunk: 128 rows x 64 bf16
 constexpr int F2_HIMG = 0, F2_MISC = 65536;
-constexpr int F2_LDS_BYTES = F2_MISC + (4 * 128 + 128 + 16 + 8 * 256) * 4;
+constexpr int F2_LDS_BYTES = F2_MISC + (4 * 128 + 128 + 16 + 8 * 256 + 3 * 256) * 4;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// Diagnostic build only (-DMMF_STAMPS): phase cycles {main loop, epilogue 1, gate phase, pooling, -, -, real time, waves}
+#ifdef MMF_STAMPS
+static __device__ unsigned long long g_bst2[8];
+__device__ inline unsigned long long real_now2() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define B2_BEGIN() unsigned long long b2_real = real_now2(), b2_prev = stamp_now(), b2_t
+#define B2_MARK(slot) do { b2_t = stamp_now(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_bst2[slot], b2_t - b2_prev); b2_prev = b2_t; } while (0)
+#define B2_COUNT() do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_bst2[7], 1ull); atomicAdd(&g_bst2[6], real_now2() - b2_real); } } while (0)
+#else
+#define B2_BEGIN()
+#define B2_MARK(slot)
+#define B2_COUNT()
+#endif
+void debug_stamps_fwd2(unsigned long long* out8) {       // overwrites out8 when this kernel ran since the last call
+#ifdef MMF_STAMPS
+  unsigned long long v[8];
+  hipMemcpyFromSymbol(v, HIP_SYMBOL(g_bst2), sizeof v);
+  if (v[7] == 0) return;
+  for (int i = 0; i < 8; ++i) out8[i] = v[i];
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_bst2), z, sizeof z);
+#else
+  (void)out8;
+#endif
+}
 
 // A-fragment load hidden from the compiler's wait bookkeeping (the x stream's LDS-DMAs share the in-order VM
 // counter; completion is counted by hand in the main loop, cdna_hip_programming.md "mixing load KINDS in one k-loop")
@@ -58,7 +87,8 @@ __device__ inline bf16x8 frag_of(const float4& v) {
 }
 
 // MFMAs of one staged x chunk (64 k) against the wave's 64 weight rows held in `wf` (k-step q, row block fb -> wf[2q + fb])
-__device__ inline void f2_chunk(const char* xs, const f32x4v (&wf)[8], f32x16 (&acc)[2][4], int r, int hh) {
+template <class Hook>
+__device__ inline void f2_chunk(const char* xs, const f32x4v (&wf)[8], f32x16 (&acc)[2][4], int r, int hh, Hook&& hook) {
   const int sw = (r >> 1) & 7;
   const char* b0 = xs + r * 128;
   float4 fx[2][4];
@@ -71,11 +101,16 @@ __device__ inline void f2_chunk(const char* xs, const f32x4v (&wf)[8], f32x16 (&
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (q + 1 < 4) rd(q + 1, (q + 1) & 1);
+    hook(q);                                               // vector-ALU work that rides in the MFMAs' shadow
+#ifdef MMF_F2_REV_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
       for (int ib = 0; ib < 4; ++ib)
         acc[fb][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(wf[2 * q + fb]), frag_of(fx[q & 1][ib]), acc[fb][ib], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -91,7 +126,20 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   float* e_l = sred + 4 * 128;                                    // [128]
   float* red = e_l + 128;                                         // [16]
   float* vred = red + 16;                                         // [8][256]
+  float* gpar = vred + 8 * 256;                                   // ba, bb, Wc: read per pass from LDS, not from memory (a load
+                                                                  // issued behind a pass's a / b stores would wait for their acknowledgement)
+  {
+    const float va = p.ba[tid], vb = p.bb[tid], vc = p.Wc[tid];
+    asm volatile("" :: "v"(va), "v"(vb), "v"(vc));
+    gpar[tid] = va; gpar[256 + tid] = vb; gpar[512 + tid] = vc;
+  }
 
+#ifdef MMF_F2_DEBUG      /* timing experiments (wrong results): phases switched off by bits of MMF_F2_DEBUG_MASK */
+  const int dbg = p.stagger;
+#else
+  constexpr int dbg = 0;
+#endif
+  B2_BEGIN();
   // ---------------- phase 1: u^T = W1 . x^T (K = L) ------------------------------------------------------------
   f32x16 acc[2][4];                                               // [feature block fb][instance block ib]
 #pragma unroll
@@ -108,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
       for (int i = 0; i < 16; ++i) acc[fb][ib][i] = bias[i];
     asm volatile("" :: "v"(bias[0]), "v"(bias[4]), "v"(bias[8]), "v"(bias[12]));   // the compiler's own waits for these loads stay in front of the hidden queue
   }
+  const uint32_t thr_h = drop_threshold(p.p_h);
+  const bool hloop = p.p_h > 0.f && p.L == 1024 && p.hash_in_loop;   // 16 chunks: keep-bits hashed inside the main loop
+  const uint32_t hbase = ((uint32_t)(row0 + r) * 256u + 64u * (uint32_t)wave + 4u * (uint32_t)hh) * 0x9E3779B1u + p.key_h + sdev;
+  uint32_t km[4] = {0u, 0u, 0u, 0u};                              // bit e = ((fb 4 + ib) 4 + g) 4 + j of word e / 32: keep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the hand-counted queue below starts empty
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -122,40 +174,78 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
       ldw_asm<0>(w[0], rw, vw0, so); ldw_asm<1024>(w[1], rw, vw0, so); ldw_asm<2048>(w[2], rw, vw0, so); ldw_asm<3072>(w[3], rw, vw0, so);
       ldw_asm<0>(w[4], rw, vw1, so); ldw_asm<1024>(w[5], rw, vw1, so); ldw_asm<2048>(w[6], rw, vw1, so); ldw_asm<3072>(w[7], rw, vw1, so);
     };
-    auto stage = [&](int kt) { return lds + (kt % 3) * F2_STAGE; };
+#ifndef MMF_F2_STAGE_BASE
+#define MMF_F2_STAGE_BASE 0
+#endif
+    auto stage = [&](int kt) { return lds + MMF_F2_STAGE_BASE + (kt % 3) * F2_STAGE; };
     const int nk = p.L / 64;                                      // even (launcher)
-    // queue order per iteration: [W(kt+1) x 8] [x(kt+2) x 4]; before chunk kt+1 is read everything up to W(kt+1) has
-    // landed (vmcnt(4)), x(kt+2) may still be in flight
+    // Queue order per iteration: [W(kt+1) x 8] [x(kt+2) x 4]; before chunk kt+1 is read everything up to W(kt+1) has landed
+    // (vmcnt(4)), x(kt+2) may still be in flight.  The loop body is BRANCH-FREE on purpose: the weight fragments are outputs
+    // of asm statements whose data arrives later, and a conditional definition would let the compiler merge old and new
+    // values with register copies placed right behind the (still unanswered) load.  The requests past the last chunk read
+    // beyond num_records (weights: zeros, no traffic) or refill a stage nobody reads any more; all are drained behind the loop.
     load_w(0, wf0);
     lx.issue(0, stage(0));
-    if (nk > 1) lx.issue(1, stage(1));
-    if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    lx.issue(1, stage(1));
+    wait_vmcnt<4>();
+    asm volatile("" : "+v"(wf0[0]), "+v"(wf0[1]), "+v"(wf0[2]), "+v"(wf0[3]), "+v"(wf0[4]), "+v"(wf0[5]), "+v"(wf0[6]), "+v"(wf0[7]));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
-      if (kt + 1 < nk) load_w(kt + 1, wnext);
-      if (kt + 2 < nk) lx.issue(kt + 2, stage(kt + 2));
-      __builtin_amdgcn_sched_barrier(0);
-      f2_chunk(stage(kt), wcur, acc, r, hh);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+    // The dropout keep-bits of the projection (model_attention_mil_path.py:21) depend on indices only: with 16 chunks they
+    // are hashed here, 8 elements per chunk between the MFMAs (the loop waits for memory, its vector ALU is idle), and the
+    // epilogue only applies them.  Element e = ((fb 4 + ib) 4 + g) 4 + j of this lane is hashed in chunk e / 8.
+    auto main_loop = [&](auto hl_c) {
+      constexpr bool HLOOP = decltype(hl_c)::value;
+      auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
+        if (!(dbg & 2)) load_w(kt + 1, wnext);
+        if (!(dbg & 1)) lx.issue(kt + 2, stage(kt + 2));
+        uint32_t bits = 0;
+        const uint32_t sC = __builtin_amdgcn_readfirstlane((uint32_t)(((kt >> 1) & 3) * 8192 + (kt >> 3) * 32 + (kt & 1) * 16) * 0x9E3779B1u);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 4)) f2_chunk(stage(kt), wcur, acc, r, hh, [&](int q) {
+          if constexpr (HLOOP) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+              const int i = 2 * q + i2;
+              uint32_t h = hbase + sC + (uint32_t)((i >> 2) * 8 + (i & 3)) * 0x9E3779B1u;
+              h ^= h >> 16; h *= 0x85EBCA6Bu;
+              h ^= h >> 13; h *= 0xC2B2AE35u;
+              h ^= h >> 16;
+              bits |= ((h >> 8) >= thr_h ? 1u : 0u) << i;
+            }
+          }
+        });
+        if constexpr (HLOOP) {
+          const uint32_t b = bits << ((kt & 3) * 8);
+          const int w = kt >> 2;
+          km[0] |= w == 0 ? b : 0u; km[1] |= w == 1 ? b : 0u; km[2] |= w == 2 ? b : 0u; km[3] |= w == 3 ? b : 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg & 3) wait_vmcnt<0>(); else wait_vmcnt<4>();
+        // the fragments are defined HERE as far as the compiler is concerned: nothing may read or move them before the wait
+        asm volatile("" : "+v"(wnext[0]), "+v"(wnext[1]), "+v"(wnext[2]), "+v"(wnext[3]), "+v"(wnext[4]), "+v"(wnext[5]), "+v"(wnext[6]), "+v"(wnext[7]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int kt = 0; kt < nk; kt += 2) {
+        iter(kt, wf0, wf1);
+        iter(kt + 1, wf1, wf0);
+      }
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-      iter(kt, wf0, wf1);
-      iter(kt + 1, wf1, wf0);
-    }
+    if (hloop) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    wait_vmcnt<0>();                                             // the two refills past the last chunk
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
 
+  B2_MARK(0);
   // ---------------- epilogue 1: h = bf16(drop(relu(u))) -> the LDS h image (B operand of phase 2, pooled operand) ----
   {
-    const uint32_t thr = drop_threshold(p.p_h);
     const float scale = p.p_h > 0.f ? 1.0f / (1.0f - p.p_h) : 1.0f;
     const uint32_t dkey = p.key_h + sdev;
-    auto epi = [&](auto drop_c) {
-      constexpr bool DROP = decltype(drop_c)::value;
+    auto epi = [&](auto mode_c) {                            // 0: no dropout, 1: keep-bits from the main loop, 2: hashed here
+      constexpr int MODE = decltype(mode_c)::value;
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
@@ -169,14 +259,17 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               y[j] = fmaxf(acc[fb][ib][4 * g + j], 0.f);
-              if constexpr (DROP) y[j] = keep(dkey, (uint32_t)(row0 + R) * 256u + (uint32_t)(f + j), thr) ? y[j] * scale : 0.f;
+              if constexpr (MODE == 1) y[j] = (km[2 * fb + (ib >> 1)] >> ((ib & 1) * 16 + 4 * g + j)) & 1u ? y[j] * scale : 0.f;
+              if constexpr (MODE == 2) y[j] = keep(dkey, (uint32_t)(row0 + R) * 256u + (uint32_t)(f + j), thr_h) ? y[j] * scale : 0.f;
             }
             const int slot = 8 * wave + 4 * fb + g;
             *reinterpret_cast<uint2*>(rowp + 16 * (slot ^ (R & 15))) = pack4(y[0], y[1], y[2], y[3]);
           }
         }
     };
-    if (p.p_h > 0.f) epi(std::true_type{}); else epi(std::false_type{});
+    if (p.p_h <= 0.f) epi(std::integral_constant<int, 0>{});
+    else if (hloop) epi(std::integral_constant<int, 1>{});
+    else epi(std::integral_constant<int, 2>{});
   }
   // the wave's gate weights of pass 0 (16 k-steps x one 32-row A block): in flight across the barrier and the h copy
   const rsrc_t rg = make_rsrc(p.wabf, 512u * 256u * 2u);
@@ -185,9 +278,10 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll
   for (int s = 0; s < 16; ++s) wg[s] = bld4(rg, vg, (unsigned)s * 1024u);
   __syncthreads();                                         // h tile complete
+  B2_MARK(1);
   // saved activations go out through buffer stores: rows beyond the bag fall outside num_records and are dropped
   const unsigned act_bytes = (unsigned)p.N * 512u;
-  if (p.h) {                                               // whole 512-byte rows per wave instruction
+  if (p.h && !(dbg & 128)) {                               // whole 512-byte rows per wave instruction
     const rsrc_t rh = make_rsrc(p.h, act_bytes);
     const int s = tid & 31;
 #pragma unroll
@@ -207,8 +301,10 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   float sc[4] = {0.f, 0.f, 0.f, 0.f};                      // score partials of instance 32 ib + r over this lane's dims
   const char* hb0 = lds + F2_HIMG + r * 512;
   const int sx = r & 15;
+  auto gate_phase = [&](auto drop_c) {                     // attention dropout on / off decided once, not per element
+  constexpr bool DROP = decltype(drop_c)::value;
 #pragma unroll 1
-  for (int ps = 0; ps < 4; ++ps) {
+  for (int ps = 0; ps < ((dbg & 8) ? 0 : 4); ++ps) {
     const int dbase = 64 * ps + 16 * wave;
     const unsigned next_w = __builtin_amdgcn_readfirstlane((unsigned)(ps + 1) * 65536u);   // pass 4 does not exist: reads as zero
     asm volatile("" ::: "memory");                         // the h fragments are re-read every pass (hoisted out of the loop they spill)
@@ -220,7 +316,11 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
       float bias[16];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
+#ifdef MMF_F2_REV_GPAR
         const float4 ta = ld4(p.ba + dbase + 8 * g + 4 * hh), tb = ld4(p.bb + dbase + 8 * g + 4 * hh), tw = ld4(p.Wc + dbase + 8 * g + 4 * hh);
+#else
+        const float4 ta = ld4(gpar + dbase + 8 * g + 4 * hh), tb = ld4(gpar + 256 + dbase + 8 * g + 4 * hh), tw = ld4(gpar + 512 + dbase + 8 * g + 4 * hh);
+#endif
         bias[4 * g] = ta.x; bias[4 * g + 1] = ta.y; bias[4 * g + 2] = ta.z; bias[4 * g + 3] = ta.w;
         bias[8 + 4 * g] = tb.x; bias[8 + 4 * g + 1] = tb.y; bias[8 + 4 * g + 2] = tb.z; bias[8 + 4 * g + 3] = tb.w;
         wc[4 * g] = tw.x; wc[4 * g + 1] = tw.y; wc[4 * g + 2] = tw.z; wc[4 * g + 3] = tw.w;
@@ -240,12 +340,15 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       if (s + 1 < 16) rdh(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);                   // the fragments of step s + 1 are on their way before step s multiplies
 #pragma unroll
       for (int ib = 0; ib < 4; ++ib)
         ag[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(wg[s]), frag_of(fh[s & 1][ib]), ag[ib], 0, 0, 0);
       wg[s] = bld4(rg, vg, next_w + (unsigned)(s * 1024));   // next pass's weights of this k-step
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- activations, a / b stores (16 contiguous bytes per lane after the half swap), score partials ----
+    if (dbg & 16) { for (int ib = 0; ib < 4; ++ib) sc[ib] += ag[ib][0] + ag[ib][15]; continue; }
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib) {
       const int R = 32 * ib + r, row = row0 + R;
@@ -255,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
         float av[4], bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          av[j] = fast_tanh(ag[ib][4 * g + j]);
+          av[j] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ag[ib][4 * g + j] * -2.885390082f)), -1.0f);   // tanh
           bv[j] = fast_sigmoid(ag[ib][8 + 4 * g + j]);
         }
         pa[2 * g] = pack2(av[0], av[1]); pa[2 * g + 1] = pack2(av[2], av[3]);
@@ -267,17 +370,24 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float ad = av[j], bd = bv[j];
-          if (drop) {
+          if constexpr (DROP) {
             ad = keep(key_a, idx + j, thr_a) ? ad * dscale : 0.f;
             bd = keep(key_b, idx + j, thr_a) ? bd * dscale : 0.f;
           }
-          sc[ib] += ad * bd * wc[4 * g + j];
+          sc[ib] = __builtin_fmaf(ad * bd, wc[4 * g + j], sc[ib]);   // spelled out: the same two roundings for every block and lane
         }
       }
-      if (p.a) {
+#ifdef MMF_F2_REV_STORE_BRANCH
+      if (p.a)
+#endif
+      {   // no branch around the stores (forward-only calls: zero-size resources drop them): the compiler can then COUNT the
+          // stores that follow a weight load in the in-order VM queue instead of waiting for every store's acknowledgement
         // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
         // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
         uint32_t oa[4], ob[4];
+#ifdef MMF_F2_NOSWAP
+        for (int q = 0; q < 4; ++q) { oa[q] = pa[q]; ob[q] = pb[q]; }
+#else
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           auto sa = __builtin_amdgcn_permlane32_swap(pa[q], pa[2 + q], false, false);
@@ -285,18 +395,28 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
           oa[q] = sa[0]; oa[2 + q] = sa[1];
           ob[q] = sb[0]; ob[2 + q] = sb[1];
         }
+#endif
+#ifdef MMF_F2_NOSTORE
+        asm volatile("" :: "v"(oa[0]), "v"(oa[1]), "v"(oa[2]), "v"(oa[3]), "v"(ob[0]), "v"(ob[1]), "v"(ob[2]), "v"(ob[3]));
+        if (false)
+#endif
+        {
         const unsigned o = (unsigned)row * 512u + (unsigned)(dbase + 8 * hh) * 2u;
         bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
         bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
+        }
       }
     }
   }
+  };
+  if (drop) gate_phase(std::true_type{}); else gate_phase(std::false_type{});
 #pragma unroll
   for (int ib = 0; ib < 4; ++ib) {
     const float s = sc[ib] + __shfl_xor(sc[ib], 32, 64);
     if (hh == 0) sred[wave * 128 + 32 * ib + r] = s;
   }
   __syncthreads();
+  B2_MARK(2);
 
   // ---------------- scores of the tile, online-softmax partial, pooling partial ----------------------------------------
   const float bc = p.bc[0];
@@ -315,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   const float lsum = wave_sum(ev);
   if (lane == 0) red[8 + wave] = lsum;
   __syncthreads();
-  {
+  if (!(dbg & 32)) {
     const int fg = tid & 31, ig = tid >> 5;                // 8 features x 16 instances per thread
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -341,6 +461,8 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     out[2 + tid] = s;
   }
   if (tid == 0) { out[0] = m; out[1] = red[8] + red[9]; }
+  B2_MARK(3);
+  B2_COUNT();
 }
 
 bool fused_fwd2_ok(int64_t N, int L, int H, int D) {
@@ -351,10 +473,20 @@ bool fused_fwd2_ok(int64_t N, int L, int H, int D) {
 int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st) {
   if (!gated || p.D != 256 || p.L % 128 != 0 || !p.w1f || !p.wabf) return MMF_ERR_SHAPE;
   p.mt_count = fused_fwd_tiles(p.N);
+  static const int dbg = getenv("MMF_F2_DEBUG_MASK") ? atoi(getenv("MMF_F2_DEBUG_MASK")) : 0;
+  static const int hl = getenv("MMF_F2_HLOOP") ? atoi(getenv("MMF_F2_HLOOP")) : 1;       // A/B switch
+  p.stagger = dbg;
+  p.hash_in_loop = hl;
   auto kern = amil_fwd_fused2_bf16_kernel;
-  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), F2_LDS_BYTES)) return e;
+  static const int lds_env = getenv("MMF_F2_LDS") ? atoi(getenv("MMF_F2_LDS")) : 0;     // experiment: > 80 KB forces one workgroup per CU
+#ifdef MMF_F2_REV_GPAR
+  const int lds_bytes = lds_env > 0 ? lds_env : F2_LDS_BYTES;       // experiment: any size (the gate parameters are not in LDS)
+#else
+  const int lds_bytes = lds_env > F2_LDS_BYTES ? lds_env : F2_LDS_BYTES;
+#endif
+  if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes)) return e;
   ProfScope ps("amil_fwd_fused_bf16_kernel", st);
-  hipLaunchKernelGGL(kern, dim3(p.mt_count), dim3(256), F2_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.mt_count), dim3(256), lds_bytes, st, p);
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 

@@ -61,7 +61,11 @@ __device__ inline unsigned lds_addr(const void* p) {       // LDS byte address o
   return (unsigned)(unsigned long long)(lds_char*)(p);
 }
 __device__ inline void dma16(const DmaRsrc& rs, unsigned lds_dst, unsigned voff, unsigned soff) {
+#ifdef MMF_DMA_M0NOP
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_nop 4"
+#else
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+#endif
                :: "s"(lds_dst), "v"(voff), "s"(rs.w), "s"(soff) : "memory");   // M0 is written and consumed inside this one statement
 }
 

@@ -39,6 +39,62 @@ def load_slide_bags(paths, pin: bool = True, dtype=None) -> torch.Tensor:
     return out
 
 
+def intersect_modalities(features_by_mod, slice_index_by_mod, modalities=None, pin: bool = True, dtype=None,
+                         require_equal: bool = True):
+    """One subject's radiology bags restricted to the slices every modality has, as datasets/dataset_survival.py:346-348
+    does it: `intersect = set.intersection(*[set(v) ...])`, then per modality the rows whose slice index is in the
+    intersection, IN THEIR STORED ORDER (`features[np.in1d(slice_index, intersect), :]`).  Pure index work: the rows
+    are gathered bit for bit.
+
+    features_by_mod[m]: [n_m x 1024] array or tensor, slice_index_by_mod[m]: [n_m] slice ids (any integer or float type).
+    `modalities` fixes the order of the returned dict (default: the order of `features_by_mod`; the reference iterates
+    `self.modalities`).  Returns {m: tensor [n x 1024]} in ONE pinned host buffer per modality (what DevicePrefetcher copies
+    asynchronously).  The model concatenates the modalities along the feature axis (models/model_attention_mil_radio.py:
+    80-82), which needs equal n; a slice id that repeats inside one modality breaks that in the reference too (torch.cat
+    raises there), so `require_equal` (default) raises ValueError here, at the point where the cause is still known."""
+    import numpy as np
+    mods = list(modalities) if modalities is not None else list(features_by_mod.keys())
+    if not mods:
+        return {}
+    idx = {m: np.asarray(slice_index_by_mod[m]).reshape(-1) for m in mods}
+    common = None
+    for m in mods:
+        u = np.unique(idx[m])
+        common = u if common is None else np.intersect1d(common, u, assume_unique=True)
+    out = {}
+    for m in mods:
+        f = features_by_mod[m]
+        f = f if torch.is_tensor(f) else torch.as_tensor(np.asarray(f))
+        if f.dim() != 2 or f.shape[0] != idx[m].shape[0]:
+            raise ValueError(f"modality {m}: features {tuple(f.shape)} do not match {idx[m].shape[0]} slice ids")
+        rows = torch.as_tensor(np.nonzero(np.isin(idx[m], common))[0])
+        dst = torch.empty((rows.numel(), f.shape[1]), dtype=dtype or f.dtype,
+                          pin_memory=bool(pin) and torch.cuda.is_available())
+        if rows.numel():
+            torch.index_select(f, 0, rows, out=dst) if dst.dtype == f.dtype else dst.copy_(f.index_select(0, rows))
+        out[m] = dst
+    if require_equal and len({t.shape[0] for t in out.values()}) > 1:
+        raise ValueError("modalities keep different numbers of slices (a slice id repeats inside one modality): "
+                         + ", ".join(f"{m}: {t.shape[0]}" for m, t in out.items()))
+    return out
+
+
+def load_radio_bags(h5_paths_by_mod, modalities=None, pin: bool = True, dtype=None):
+    """datasets/dataset_survival.py:339-348 for one subject: read `features` and `slice_index` of every modality's .h5
+    file, keep the common slices.  Needs h5py (absent from the build image: the read is three lines and untested here; the
+    index work, which is what must be exact, is `intersect_modalities`)."""
+    try:
+        import h5py
+    except ImportError as e:      # fail loudly, as everything on this path does
+        raise ImportError("load_radio_bags needs h5py; pass arrays to feed.intersect_modalities instead") from e
+    feats, idx = {}, {}
+    for m, path in h5_paths_by_mod.items():
+        with h5py.File(path, "r") as f:
+            feats[m] = f["features"][:]
+            idx[m] = f["slice_index"][:]
+    return intersect_modalities(feats, idx, modalities, pin, dtype)
+
+
 def _pin(t: torch.Tensor) -> torch.Tensor:
     if not torch.is_tensor(t) or t.is_cuda:
         return t

@@ -25,6 +25,11 @@ from multimodalfusion_amd import build as B   # noqa: E402
 
 VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
+            "f2base": ["-DMMF_F2_STAGE_BASE=16384"], "f2nop": ["-DMMF_DMA_M0NOP"],
+            "f2noslp": ["-fno-slp-vectorize"],
+            "f2noswap": ["-DMMF_F2_NOSWAP"], "f2nostore": ["-DMMF_F2_NOSTORE"],
+            "f2r1": ["-DMMF_F2_REV_STORE_BRANCH"], "f2r2": ["-DMMF_F2_REV_GPAR"], "f2r3": ["-DMMF_F2_REV_SCHED"],
+            "f2dbg": ["-DMMF_F2_DEBUG"],     # MMF_F2_DEBUG_MASK leaves phases of the bf16 fused forward out (mmf_amil_bf16_fwd2.hip)
             "nostore": ["-DMMF_DIAG_NOSTORE"], "noepi": ["-DMMF_DIAG_NOEPI"],
             "nofrag": ["-DMMF_DIAG_NOLOAD", "-DMMF_DIAG_NOFRAG"],
             "epi1": ["-DMMF_DIAG_EPI1"], "nogload": ["-DMMF_DIAG_NOGLOAD"],
@@ -48,7 +53,7 @@ def main():
         for s in B.SOURCES:
             obj = os.path.join(objdir, s.replace(".hip", ".o"))
             objs.append(obj)
-            jobs.append([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj])
+            jobs.append([B.HIPCC] + B.FLAGS + B.FILE_FLAGS.get(s, []) + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj])
         with ThreadPoolExecutor(max_workers=4) as ex:
             for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
                 if r.returncode != 0:
