@@ -579,7 +579,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        # RCCL exchanges buffers between the ranks' processes through IPC handles; this pool's host driver supports the
+        # dmabuf form only (with the legacy form hipIpcGetMemHandle fails with "invalid argument").  The image exports the
+        # variable already; setdefault keeps a launcher's explicit choice.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("MMF_BENCH_COUNT_COLLECTIVES"):
+            # test hook (tests/test_gpu_bench_dp.py): every collective this rank issues is counted and written out at exit
+            _n = {"all_reduce": 0, "barrier": 0}
+            _ar, _ba = dist.all_reduce, dist.barrier
+
+            def _count_ar(*a, **k):
+                _n["all_reduce"] += 1
+                return _ar(*a, **k)
+
+            def _count_ba(*a, **k):
+                _n["barrier"] += 1
+                return _ba(*a, **k)
+            dist.all_reduce, dist.barrier = _count_ar, _count_ba
+            import atexit
+            atexit.register(lambda: open(os.environ["MMF_BENCH_COUNT_COLLECTIVES"] + f".rank{rank}", "w").write(json.dumps(_n)))
         if os.environ.get("MMF_BENCH_REHEARSAL") == "1":
             # rehearsal of the multi-process path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
             local = 0

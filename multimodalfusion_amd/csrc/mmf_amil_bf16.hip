@@ -153,7 +153,7 @@ __global__ __launch_bounds__(T::NT) void linear_bf16_dma_kernel(LinearBfParams p
       const int row = row0 + r + 8 * t;
       if (row >= p.M) continue;
       float y[4] = {v[t].x + b4.x, v[t].y + b4.y, v[t].z + b4.z, v[t].w + b4.w};
-      const uint32_t idx = ((uint32_t)row + p.row_base) * (uint32_t)p.N + (uint32_t)col;
+      const uint32_t idx = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         y[e] = fmaxf(y[e], 0.f);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(T::NT) void gate_bf16_kernel(GateBfParams p) {
             if constexpr (GATED) *reinterpret_cast<uint2*>(p.b + o) = pb;
           }
           const float wc[4] = {wc4.x, wc4.y, wc4.z, wc4.w};
-          const uint32_t idx = ((uint32_t)row + p.row_base) * (uint32_t)p.D + (uint32_t)d;
+          const uint32_t idx = (uint32_t)row * (uint32_t)p.D + (uint32_t)d;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float ad = av[e], bd = bv[e];
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void pool_partial_bf16_kernel(PoolBfParams pb)
   }
 }
 
-int launch_pool_partial_bf16(PoolBfParams& pb, hipStream_t st) {
+static int launch_pool_partial_bf16(PoolBfParams& pb, hipStream_t st) {
   PoolParams& p = pb.base;
   if (p.H != 256 && p.H != 512 && p.H != 1024) return MMF_ERR_SHAPE;
   p.n_groups = pool_groups(p.N);

@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   // the wave's gate weights of pass 0 (16 k-steps x one 32-row A block): in flight across the barrier and the h copy
   const rsrc_t rg = make_rsrc(p.wabf, 512u * 256u * 2u);
   const unsigned vg = (unsigned)lane * 16u + (unsigned)wave * 16384u;
-  float4 wg[16];
+  float4 wg0[16], wg1[16];                                 // weights of the even / odd passes
 #pragma unroll
-  for (int s = 0; s < 16; ++s) wg[s] = bld4(rg, vg, (unsigned)s * 1024u);
+  for (int s = 0; s < 16; ++s) wg0[s] = bld4(rg, vg, (unsigned)s * 1024u);
   __syncthreads();                                         // h tile complete
   B2_MARK(1);
   // saved activations go out through buffer stores: rows beyond the bag fall outside num_records and are dropped
@@ -293,7 +293,15 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   }
   const rsrc_t rsa = make_rsrc(p.a ? p.a : p.h, p.a ? act_bytes : 0u), rsb = make_rsrc(p.a ? p.b : p.h, p.a ? act_bytes : 0u);
 
-  // ---------------- phase 2: [a ; b]^T of 16 dims per pass = (32 weight rows) . h^T, four passes -----------------------
+  // ---------------- phase 2: [a ; b]^T = (gate weights) . h^T as a software pipeline -------------------------------------
+  // 16 blocks (pass ps = 0..3: attention dims 64 ps + 16 w .. + 15; instance block ib = 0..3).  A block is ONE 32 x 32
+  // accumulator: 16 MFMAs along K = 256 (rows 0-15 of the A block are Wa, rows 16-31 Wb of the same dims: accumulator
+  // i < 8 is pre-tanh, i >= 8 pre-sigmoid of dim dbase + 8 ((i >> 2) & 1) + 4 hh + (i & 3)), then ~150 vector
+  // instructions: tanh / sigmoid, bf16 rounding, a / b stores (16 contiguous bytes per lane after the half swap), score
+  // partial.  A SIMD does not run one wave's vector work beside its partner's dense MFMA stream (tools/coissue.hip), but
+  // it does issue a wave's OWN vector instructions in the shadow of that wave's MFMAs: so the MFMAs of block k are issued
+  // in the same region as the activations of block k - 1 (accumulators alternate), and the weights of the next pass
+  // (second register set) arrive while this pass multiplies.
   const uint32_t thr_a = drop_threshold(p.p_att);
   const bool drop = p.p_att > 0.f;
   const float dscale = drop ? 1.0f / (1.0f - p.p_att) : 1.0f;
@@ -302,55 +310,34 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   const char* hb0 = lds + F2_HIMG + r * 512;
   const int sx = r & 15;
   auto gate_phase = [&](auto drop_c) {                     // attention dropout on / off decided once, not per element
-  constexpr bool DROP = decltype(drop_c)::value;
-#pragma unroll 1
-  for (int ps = 0; ps < ((dbg & 8) ? 0 : 4); ++ps) {
-    const int dbase = 64 * ps + 16 * wave;
-    const unsigned next_w = __builtin_amdgcn_readfirstlane((unsigned)(ps + 1) * 65536u);   // pass 4 does not exist: reads as zero
-    asm volatile("" ::: "memory");                         // the h fragments are re-read every pass (hoisted out of the loop they spill)
-    f32x16 ag[4];
-    float wc[8];
-    {
-      // rows 0-15 of the A block are Wa (dims dbase ..), rows 16-31 Wb: accumulator i < 8 is pre-tanh, i >= 8 pre-sigmoid
-      // of dim dbase + 8 ((i >> 2) & 1) + 4 hh + (i & 3)
-      float bias[16];
+    constexpr bool DROP = decltype(drop_c)::value;
+    f32x16 ag0, ag1;                                       // accumulators of the even / odd instance blocks
+    // MFMAs of block (dbase, ib) into `acc`, which starts as the biases (read from LDS straight into the accumulator)
+    auto mm = [&](const float4 (&w)[16], f32x16& acc, int dbase, int ib) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-#ifdef MMF_F2_REV_GPAR
-        const float4 ta = ld4(p.ba + dbase + 8 * g + 4 * hh), tb = ld4(p.bb + dbase + 8 * g + 4 * hh), tw = ld4(p.Wc + dbase + 8 * g + 4 * hh);
-#else
-        const float4 ta = ld4(gpar + dbase + 8 * g + 4 * hh), tb = ld4(gpar + 256 + dbase + 8 * g + 4 * hh), tw = ld4(gpar + 512 + dbase + 8 * g + 4 * hh);
-#endif
-        bias[4 * g] = ta.x; bias[4 * g + 1] = ta.y; bias[4 * g + 2] = ta.z; bias[4 * g + 3] = ta.w;
-        bias[8 + 4 * g] = tb.x; bias[8 + 4 * g + 1] = tb.y; bias[8 + 4 * g + 2] = tb.z; bias[8 + 4 * g + 3] = tb.w;
+        const float4 ta = ld4(gpar + dbase + 8 * g + 4 * hh), tb = ld4(gpar + 256 + dbase + 8 * g + 4 * hh);
+        acc[4 * g] = ta.x; acc[4 * g + 1] = ta.y; acc[4 * g + 2] = ta.z; acc[4 * g + 3] = ta.w;
+        acc[8 + 4 * g] = tb.x; acc[8 + 4 * g + 1] = tb.y; acc[8 + 4 * g + 2] = tb.z; acc[8 + 4 * g + 3] = tb.w;
+      }
+      float4 fh[2];
+      const char* hb = hb0 + ib * 32 * 512;
+      fh[0] = *reinterpret_cast<const float4*>(hb + 16 * ((0 + hh) ^ sx));
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + 1 < 16) fh[(s + 1) & 1] = *reinterpret_cast<const float4*>(hb + 16 * ((2 * (s + 1) + hh) ^ sx));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(w[s]), frag_of(fh[s & 1]), acc, 0, 0, 0);
+      }
+    };
+    // activations of block (dbase, ib) from `acc`
+    auto act = [&](const f32x16& acc, int dbase, int ib) {
+      if (dbg & 16) { sc[ib] += acc[0] + acc[15]; return; }
+      float wc[8];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 tw = ld4(gpar + 512 + dbase + 8 * g + 4 * hh);
         wc[4 * g] = tw.x; wc[4 * g + 1] = tw.y; wc[4 * g + 2] = tw.z; wc[4 * g + 3] = tw.w;
       }
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ag[ib][i] = bias[i];
-    }
-    float4 fh[2][4];
-    auto rdh = [&](int s, int buf) {
-      const int o = 16 * ((2 * s + hh) ^ sx);
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib) fh[buf][ib] = *reinterpret_cast<const float4*>(hb0 + ib * 32 * 512 + o);
-    };
-    rdh(0, 0);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      if (s + 1 < 16) rdh(s + 1, (s + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);                   // the fragments of step s + 1 are on their way before step s multiplies
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib)
-        ag[ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(wg[s]), frag_of(fh[s & 1][ib]), ag[ib], 0, 0, 0);
-      wg[s] = bld4(rg, vg, next_w + (unsigned)(s * 1024));   // next pass's weights of this k-step
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- activations, a / b stores (16 contiguous bytes per lane after the half swap), score partials ----
-    if (dbg & 16) { for (int ib = 0; ib < 4; ++ib) sc[ib] += ag[ib][0] + ag[ib][15]; continue; }
-#pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
       const int R = 32 * ib + r, row = row0 + R;
       uint32_t pa[4], pb[4];                               // [2 g + (0: dims 0-1, 1: dims 2-3 of the group)]
 #pragma unroll
@@ -358,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
         float av[4], bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          av[j] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ag[ib][4 * g + j] * -2.885390082f)), -1.0f);   // tanh
-          bv[j] = fast_sigmoid(ag[ib][8 + 4 * g + j]);
+          av[j] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 * g + j] * -2.885390082f)), -1.0f);   // tanh
+          bv[j] = fast_sigmoid(acc[8 + 4 * g + j]);
         }
         pa[2 * g] = pack2(av[0], av[1]); pa[2 * g + 1] = pack2(av[2], av[3]);
         pb[2 * g] = pack2(bv[0], bv[1]); pb[2 * g + 1] = pack2(bv[2], bv[3]);
@@ -377,17 +364,10 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
           sc[ib] = __builtin_fmaf(ad * bd, wc[4 * g + j], sc[ib]);   // spelled out: the same two roundings for every block and lane
         }
       }
-#ifdef MMF_F2_REV_STORE_BRANCH
-      if (p.a)
-#endif
-      {   // no branch around the stores (forward-only calls: zero-size resources drop them): the compiler can then COUNT the
-          // stores that follow a weight load in the in-order VM queue instead of waiting for every store's acknowledgement
+      {   // no branch (forward-only calls: zero-size resources drop the stores): one scheduling region per block
         // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
         // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
         uint32_t oa[4], ob[4];
-#ifdef MMF_F2_NOSWAP
-        for (int q = 0; q < 4; ++q) { oa[q] = pa[q]; ob[q] = pb[q]; }
-#else
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           auto sa = __builtin_amdgcn_permlane32_swap(pa[q], pa[2 + q], false, false);
@@ -395,19 +375,46 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
           oa[q] = sa[0]; oa[2 + q] = sa[1];
           ob[q] = sb[0]; ob[2 + q] = sb[1];
         }
-#endif
-#ifdef MMF_F2_NOSTORE
-        asm volatile("" :: "v"(oa[0]), "v"(oa[1]), "v"(oa[2]), "v"(oa[3]), "v"(ob[0]), "v"(ob[1]), "v"(ob[2]), "v"(ob[3]));
-        if (false)
-#endif
-        {
         const unsigned o = (unsigned)row * 512u + (unsigned)(dbase + 8 * hh) * 2u;
         bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
         bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
-        }
       }
+    };
+    // one pass: its four blocks multiply while the previous block's activations are taken and the next pass's weights load
+    auto pass = [&](int ps, const float4 (&w)[16], float4 (&wn)[16]) {
+      const int dbase = 64 * ps + 16 * wave;
+      asm volatile("" ::: "memory");                       // gate parameters and h fragments are re-read every pass
+      const unsigned nw = __builtin_amdgcn_readfirstlane((unsigned)(ps + 1) * 65536u);   // pass 4 does not exist: reads as zero
+      __builtin_amdgcn_sched_barrier(0);
+      mm(w, ag0, dbase, 0);
+      if (ps > 0) act(ag1, dbase - 64, 3);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
+      __builtin_amdgcn_sched_barrier(0);
+      mm(w, ag1, dbase, 1);
+      act(ag0, dbase, 0);
+#pragma unroll
+      for (int s = 4; s < 8; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
+      __builtin_amdgcn_sched_barrier(0);
+      mm(w, ag0, dbase, 2);
+      act(ag1, dbase, 1);
+#pragma unroll
+      for (int s = 8; s < 12; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
+      __builtin_amdgcn_sched_barrier(0);
+      mm(w, ag1, dbase, 3);
+      act(ag0, dbase, 2);
+#pragma unroll
+      for (int s = 12; s < 16; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (!(dbg & 8)) {
+#pragma unroll 1
+      for (int p2 = 0; p2 < 2; ++p2) {
+        pass(2 * p2, wg0, wg1);
+        pass(2 * p2 + 1, wg1, wg0);
+      }
+      act(ag1, 192 + 16 * wave, 3);
     }
-  }
   };
   if (drop) gate_phase(std::true_type{}); else gate_phase(std::false_type{});
 #pragma unroll

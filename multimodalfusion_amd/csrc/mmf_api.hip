@@ -64,7 +64,8 @@ void prof_begin(const char* name, hipStream_t st) {
     return hipEventCreate(&e) == hipSuccess;
   };
   mmf_trace::Rec r{name, nullptr, nullptr};
-  if (!take(r.a) || !take(r.b)) return;
+  if (!take(r.a)) return;
+  if (!take(r.b)) { t->pool.push_back(r.a); return; }     // the first event goes back to the pool, not lost
   hipEventRecord(r.a, st);
   t->recs.push_back(r);
 }

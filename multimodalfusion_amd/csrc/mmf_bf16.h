@@ -52,7 +52,6 @@ struct LinearBfParams {    // y[M x N] = bf16(drop(relu(x[M x K] . W[N x K]^T + 
   int64_t M; int N, K;
   float drop_p; uint32_t drop_key; const uint32_t* seed_dev;
   int mt_count, nt_count;
-  uint32_t row_base;       // bag row of x's row 0 (dropout hash index): a launch may cover a row range of the bag
 };
 
 struct GateBfParams {
@@ -64,7 +63,6 @@ struct GateBfParams {
   int64_t N; int H, D, gated;
   float drop_p; uint32_t key_a, key_b; const uint32_t* seed_dev;
   int mt_count, nt_count;
-  uint32_t row_base;
 };
 
 struct PoolBfParams { PoolParams base; const bf16_t* h; };
@@ -106,7 +104,6 @@ int launch_linear_bf16(LinearBfParams p, hipStream_t st);
 int gate_parts_bf16(int D, int gated);
 int launch_gate_bf16(GateBfParams p, hipStream_t st);
 int launch_pool_bf16(PoolBfParams p, hipStream_t st);
-int launch_pool_partial_bf16(PoolBfParams& p, hipStream_t st);   // partials only; sets p.base.n_groups
 struct FusedFwdParams {     // fused forward (H = 256): instance projection + gate scoring + pooling partials
   const bf16_t* x; const bf16_t* w1; const float* b1;
   const bf16_t *Wa, *Wb; const float *ba, *bb, *Wc, *bc;

@@ -66,12 +66,26 @@ def _skip(mode, radio_features, path_features, genomic_features):
 
 
 def _fused_step_ok(model, loss_fn, feats):
-    """One bag = one C-ABI call (model.nll_step): the pathology head with the stock NLLSurvLoss, a single bag tensor,
-    no autograd hooks that a graph-free step would bypass."""
-    return (type(loss_fn) is NLLSurvLoss and hasattr(model, "nll_step") and torch.is_tensor(feats.get("path_features"))
-            and feats["path_features"].dim() == 2 and feats["path_features"].is_cuda
-            and not model._forward_hooks and not model._forward_pre_hooks and not model._backward_hooks
-            and all(p.requires_grad for p in model.parameters()))
+    """One bag = one C-ABI call (model.nll_step).  Only where that is exactly what `model(**feats)` + the stock loss would
+    compute: the pathology head ITSELF (a subclass that overrides forward(), or any module / global hook, would be bypassed
+    by a graph-free step -- those take the autograd path), the stock NLLSurvLoss, one 2-D fp32 / bf16 bag on the GPU, a
+    classifier the kernel's single-workgroup tail holds (<= 32 classes), every parameter trainable."""
+    from ..models.model_attention_mil_path import MIL_Attention_fc_surv_path
+    import torch.nn.modules.module as tm
+    x = feats.get("path_features")
+    if not (type(loss_fn) is NLLSurvLoss and torch.is_tensor(x) and x.dim() == 2 and x.is_cuda
+            and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    if type(model).forward is not MIL_Attention_fc_surv_path.forward or not hasattr(model, "nll_step"):
+        return False
+    if getattr(getattr(model, "classifier", None), "out_features", 1 << 30) > 32:
+        return False
+    hooked = lambda m: bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None))
+    if any(hooked(m) for m in model.modules()):
+        return False
+    if tm._global_forward_hooks or tm._global_forward_pre_hooks or tm._global_backward_hooks or getattr(tm, "_global_backward_pre_hooks", None):
+        return False
+    return all(p.requires_grad for p in model.parameters())
 
 
 class _Window:
@@ -203,6 +217,11 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
         n_pos += 1
         skipped = _skip(mode, radio_features, path_features, genomic_features)
         if not skipped:
+            if isinstance(loss_fn, NLLSurvLoss) and torch.is_tensor(label) and not label.is_cuda and label.numel() \
+                    and (int(label.min()) < 0 or int(label.max()) >= n_classes):
+                # the reference's gather (utils/loss_utils.py:30-33) raises on such a label; on the device the kernels
+                # would write a NaN loss instead, which only shows in the epoch mean -- so check while it is on the host
+                raise IndexError(f"survival bin label {label.tolist()} outside [0, {n_classes})")
             feats, label, c = _to_device(radio_features, path_features, genomic_features, label, c, device)
 
             def forward_loss():

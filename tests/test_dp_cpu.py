@@ -243,3 +243,47 @@ def test_rank_shard_reads_only_its_own_bags():
     assert got == [1, 3, 5, 7] and ds.seen == got and sh.n_total == 9
     assert [sh.position(i) for i in range(4)] == got
     assert list(RankShard(list(range(9)), 0, 4)) == [0, 4, 8]
+
+
+def test_out_of_range_label_raises_like_the_reference_gather():
+    """ADVICE r2: labels reach the kernels on the device, where a bin outside [0, n_classes) would only produce a NaN loss;
+    the reference's gather (utils/loss_utils.py:30-33) raises IndexError -- the loop checks while the label is on the host."""
+    from multimodalfusion_amd.utils import core_utils
+    model = _StubHead()
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    good = ({"T1": torch.zeros(1, 1)}, torch.randn(5, 16), torch.zeros(1, 4), torch.tensor([3]), np.array([1.0]), torch.tensor([0.0]))
+    for bad_label in (4, -1):
+        bad = good[:3] + (torch.tensor([bad_label]),) + good[4:]
+        with pytest.raises(IndexError):
+            core_utils.train_loop_survival(0, model, [good, bad], opt, 4, "path", loss_fn=_stub_loss(), gc=1)
+
+
+def test_one_call_step_is_taken_only_for_the_stock_head():
+    """a subclass that overrides forward(), a hooked module or a non-stock loss must take the autograd path (the
+    graph-free one-call step would silently train the base computation).  Checked on the predicate itself (no GPU needed:
+    the tensor only has to claim to be a CUDA tensor)."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils import core_utils
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+
+    class FakeCuda(torch.Tensor):
+        @property
+        def is_cuda(self):
+            return True
+
+    x = torch.randn(4, 1024).as_subclass(FakeCuda)
+    feats = {"path_features": x}
+    stock = MIL_Attention_fc_surv_path(n_classes=4)
+    assert core_utils._fused_step_ok(stock, NLLSurvLoss(alpha=0.0), feats)
+
+    class Tweaked(MIL_Attention_fc_surv_path):
+        def forward(self, **kw):
+            return super().forward(**kw)
+
+    assert not core_utils._fused_step_ok(Tweaked(n_classes=4), NLLSurvLoss(alpha=0.0), feats)
+    assert not core_utils._fused_step_ok(MIL_Attention_fc_surv_path(n_classes=40), NLLSurvLoss(alpha=0.0), feats)   # > 32 classes
+    assert not core_utils._fused_step_ok(stock, _stub_loss(), feats)                                                 # not the stock loss
+    hooked = MIL_Attention_fc_surv_path(n_classes=4)
+    hooked.classifier.register_forward_hook(lambda m, i, o: None)                                                    # a SUB-module hook
+    assert not core_utils._fused_step_ok(hooked, NLLSurvLoss(alpha=0.0), feats)
+    assert not core_utils._fused_step_ok(stock, NLLSurvLoss(alpha=0.0), {"path_features": x.to(torch.float64).as_subclass(FakeCuda)})

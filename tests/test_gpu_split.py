@@ -3,7 +3,7 @@ the bf16 matrix cores with every fp32 operand split into three bf16 values (six 
 
 Two bars:
   * the same bars as the exact-fp32 path (tests/test_gpu_path.py) against the live fp64 oracle, on bags that take the
-    split tiles (wide row tiles + 256x256 split-K tile from 16,384 instances, 64-row tiles + 128x128 split-K tile
+    split tiles (wide row tiles + 256x256 split-K tile from 20,480 instances, 64-row tiles + 128x128 split-K tile
     below), ragged, with and without the dropout sites;
   * the claim the mode rests on -- fp32-equivalent accuracy: its error against the fp64 oracle is compared with the
     exact-fp32 path's error on the same inputs, output by output (it must not exceed 2 x that error + rounding noise).
