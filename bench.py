@@ -439,25 +439,49 @@ def other_configs_leg(dev, steps, warmup, gen):
         ms = 1e3 * (time.perf_counter() - t0) / steps
         return {"ms_per_step": ms, "bags_per_s": 1e3 / ms}
 
-    def stepper(model, kw, loss_of):
+    def stepper(model, kw, loss_of, static_grads=False):
         params = list(model.parameters())
+        if static_grads:                      # hipGraph capture needs the gradients at fixed addresses
+            for p in params:
+                p.grad = torch.zeros_like(p)
 
         def fn():
             for p in params:
-                p.grad = None
+                if static_grads:
+                    p.grad.zero_()
+                else:
+                    p.grad = None
             loss_of(model(**kw)).backward()
         return fn
+
+    def both(model, kw, loss_of):
+        """Eager (Python + autograd + ~40-60 launches issued from the host per step: these steps are HOST-bound) and the same
+        step captured into one hipGraph (graph.GraphedStep: device-resident dropout seed, fresh masks per replay), which
+        takes the host off the critical path -- the figure that says what the kernels themselves cost."""
+        from multimodalfusion_amd.graph import GraphedStep
+        res = timeit(stepper(model, kw, loss_of))
+        try:
+            gs = GraphedStep(stepper(model, kw, loss_of, static_grads=True))
+            g = timeit(gs)
+            res["graphed_ms_per_step"] = g["ms_per_step"]
+            res["graphed_bags_per_s"] = g["bags_per_s"]
+            gs.close()
+        except Exception as e:                # capture is an optimisation: report why it was not available
+            res["graphed_error"] = f"{type(e).__name__}: {e}"[:200]
+            torch.cuda.synchronize()
+        for p in model.parameters():
+            p.grad = None
+        return res
 
     out = {}
     torch.manual_seed(1)
     rx = {m: rn(512, 1024) for m in MODS}
     radio = MIL_Attention_fc_surv_radio(n_classes=4).to(dev).train()
-    out["config3_radio_4x512x1024"] = timeit(stepper(radio, rx, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)))
+    out["config3_radio_4x512x1024"] = both(radio, rx, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
     omic = MaxNet(input_dim=36, bag_loss="cox_surv").to(dev).train()
     ot = torch.rand(128, dtype=torch.float64) * 100
     oc = (torch.rand(128, device=dev, generator=gen) < 0.5).float()
-    out["config3_omic_maxnet_B128_cox"] = timeit(stepper(omic, {"genomic_features": rn(128, 36)},
-                                                         lambda r: cox(risks=r[0], times=ot, c=oc)))
+    out["config3_omic_maxnet_B128_cox"] = both(omic, {"genomic_features": rn(128, 36)}, lambda r: cox(risks=r[0], times=ot, c=oc))
     del radio, omic
     for tag, n, dt in (("config4_mm_50k_f32", 50_000, torch.float32), ("config5_mm_100k_bf16", 100_000, torch.bfloat16)):
         xp = rn(n, 1024).to(dt)
@@ -466,7 +490,7 @@ def other_configs_leg(dev, steps, warmup, gen):
             kw = dict(rx)
             kw["path_features"] = xp
             kw["genomic_features"] = rn(80)
-            out[f"{tag}_{fusion}"] = timeit(stepper(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)))
+            out[f"{tag}_{fusion}"] = both(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
             del mm
         del xp
     return out

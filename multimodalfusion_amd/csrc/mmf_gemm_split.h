@@ -45,9 +45,14 @@ __device__ inline uint32_t cvt_pk_bf16(float lo, float hi) {       // v_cvt_pk_b
   bf16x2_t v = {(__bf16)lo, (__bf16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
-// two fp32 values -> three packed bf16 pairs
+// two fp32 values -> three packed bf16 pairs.  The first plane is taken from the value CLAMPED to the largest finite bf16
+// (3.3895e38): rounding to nearest turns a finite fp32 value beyond it (up to FLT_MAX) into an infinite plane, and
+// inf * 0 = NaN where the exact-fp32 path stays finite.  The remainder is taken from the unclamped value, so the three
+// planes still sum to it exactly (the clamp moves the first plane by less than one of its ulps).  One v_med3_f32 per value.
+// (A truncated first plane would do it for free but biases the dropped cross terms: 3x the error, tests/test_split_math_cpu.py.)
 __device__ inline void split_pair(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-  p0 = cvt_pk_bf16(x0, x1);
+  constexpr float BF16_MAX = 3.3895313892515355e38f;      // 0x7F7F0000
+  p0 = cvt_pk_bf16(__builtin_amdgcn_fmed3f(x0, -BF16_MAX, BF16_MAX), __builtin_amdgcn_fmed3f(x1, -BF16_MAX, BF16_MAX));
   float r0 = x0 - __uint_as_float(p0 << 16), r1 = x1 - __uint_as_float(p0 & 0xFFFF0000u);
   p1 = cvt_pk_bf16(r0, r1);
   r0 -= __uint_as_float(p1 << 16); r1 -= __uint_as_float(p1 & 0xFFFF0000u);

@@ -29,10 +29,34 @@ def amil_masks(seed, N, H, D, gated, dropout, dtype=np.float64):
     return m
 
 
+def shape_bag(x, kind):
+    """Other input distributions than the generator's N(0, 1), derived from it deterministically (fp32 in, fp32 out):
+      relu       max(x, 0): non-negative, half the entries zero -- what pooled post-ReLU ResNet features look like;
+      lognormal  10 ** clip(2.5 x - 1, -6, 4): magnitudes from 1e-6 to 1e4 in one bag, heavy right tail;
+      edge       N(0, 1) with a sprinkle of fp32 denormals (1e-40), exact zeros, and -- in feature column 0 only, whose
+                 first-layer weights the test zeroes -- values beyond the largest bf16 (3.39e38 .. FLT_MAX)."""
+    if not kind:
+        return x
+    x = np.asarray(x, np.float32)
+    if kind == "relu":
+        return np.maximum(x, np.float32(0))
+    if kind == "lognormal":
+        return np.power(np.float32(10), np.clip(np.float32(2.5) * x - np.float32(1), -6, 4)).astype(np.float32)
+    if kind == "edge":
+        y = x.copy()
+        flat = y.reshape(-1)
+        flat[::97] = np.float32(1e-40)
+        flat[5::389] = np.float32(-2e-41)
+        flat[11::211] = np.float32(0)
+        y[:, 0] = np.where(np.arange(y.shape[0]) % 2 == 0, np.float32(3.4028234e38), np.float32(-3.39e38))
+        return y
+    raise ValueError(kind)
+
+
 def path_inputs(m):
     sd = gen.path_state_dict(seed=m["seed"], gated=m["gated"], size=m["size"], n_classes=m["K"],
                              dropout=m["dropout"], bias_std=m["bias_std"])
-    x = gen.bag(m["x_seed"], m["N"])
+    x = shape_bag(gen.bag(m["x_seed"], m["N"]), m.get("x_kind"))
     masks = None
     if m["train"]:
         H, D = gen.SIZE_DICT[m["size"]][1:]

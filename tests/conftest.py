@@ -45,23 +45,40 @@ def golden():
     return get
 
 
-def check_summary(g, prefix, arr, rtol, atol):
-    """Compare an array against a fixture entry written by oracle.gen_golden.summarize()."""
+def check_summary(g, prefix, arr, rtol, atol, kink_rows=None):
+    """Compare an array against a fixture entry written by oracle.gen_golden.summarize().
+
+    kink_rows (first-layer gradients only; tests/test_gpu_path.py: relu_kink_units): rows of a [H x L] / [H] gradient whose
+    hidden unit has, for some instance of the bag, an fp64 pre-activation within fp32 rounding of the ReLU kink.  relu'(u)
+    there legitimately differs between two fp32 arithmetics (and between fp32 and fp64), so entries of THOSE rows may miss
+    the bar by at most 1 % of the tensor's max -- the same allowance every live-oracle comparison of the suite makes."""
     from oracle.gen_golden import sample_idx
     a = np.asarray(arr, dtype=np.float64).reshape(-1)
     scale = max(float(g[prefix + "/absmax"]), 1e-30)
     tol = atol + rtol * scale
+    rows = np.asarray(arr).shape[0] if np.asarray(arr).ndim >= 1 else 1
+    per_row = max(a.size // max(rows, 1), 1)
+    kink = np.zeros(a.size, dtype=bool)
+    for r in (kink_rows or ()):
+        kink[r * per_row:(r + 1) * per_row] = True
+
+    def judge(err, mask, what):
+        plain = err[~mask].max() if (~mask).any() else 0.0
+        assert plain <= tol, f"{prefix}: {what} max abs err {plain:.3e} > {tol:.3e}"
+        if mask.any():
+            assert err[mask].max() <= max(tol, 1e-2 * scale), f"{prefix}: {what} kink-row err {err[mask].max():.3e} > 1 % of {scale:.3e}"
+
     if g.has(prefix + "/full"):
         ref = g[prefix + "/full"]
         assert ref.shape == a.shape, (prefix, ref.shape, a.shape)
-        err = np.abs(a - ref).max() if a.size else 0.0
-        assert err <= tol, f"{prefix}: max abs err {err:.3e} > {tol:.3e}"
+        if a.size:
+            judge(np.abs(a - ref), kink, "")
     else:
         ref = g[prefix + "/sample"]
-        got = a[sample_idx(a.size)]
-        err = np.abs(got - ref).max()
-        assert err <= tol, f"{prefix}: sampled max abs err {err:.3e} > {tol:.3e}"
+        idx = sample_idx(a.size)
+        judge(np.abs(a[idx] - ref), kink[idx], "sampled")
     l2 = float(g[prefix + "/l2"])
     got_l2 = float(np.sqrt((a * a).sum()))
-    assert abs(got_l2 - l2) <= atol * np.sqrt(max(a.size, 1)) + rtol * max(l2, 1e-30) * 10, \
+    slack = 1e-2 * scale * np.sqrt(float(kink.sum())) if kink.any() else 0.0
+    assert abs(got_l2 - l2) <= atol * np.sqrt(max(a.size, 1)) + rtol * max(l2, 1e-30) * 10 + slack, \
         f"{prefix}: l2 {got_l2} vs {l2}"

@@ -43,7 +43,9 @@ def test_step_matches_oracle_on_golden_cases(golden, monkeypatch):
         if m["N"] > 2000:
             continue
         res, _ = run_step(m, monkeypatch)
-        compare(res, cases.run_path(m), name + "/step")
+        from test_gpu_path import relu_kink_units
+        sd, x, _ = cases.path_inputs(m)
+        compare(res, cases.run_path(m), name + "/step", kink_units=relu_kink_units(sd, x))
         assert np.array_equal(res["Y_hat"], g[name + "/f64/Y_hat"])
         n += 1
     assert n >= 8

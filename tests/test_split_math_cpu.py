@@ -1,7 +1,8 @@
 """CPU check of the arithmetic behind mmf_amil_desc::gemm = MMF_GEMM_BF16X3 (csrc/mmf_gemm_split.h), restated with
-torch.bfloat16 (round to nearest even, what v_cvt_pk_bf16_f32 does):
+torch.bfloat16 (round to nearest even, what v_cvt_pk_bf16_f32 does); the first plane is taken from the value clamped to the
+largest finite bf16, so that a finite fp32 value never splits into an infinite plane:
 
-  * an fp32 value is the EXACT sum of three bf16 values a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1);
+  * an fp32 value is the EXACT sum of three bf16 values a0 = bf16(clamp(a)), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1);
   * every product of two bf16 values is exact in fp32;
   * the six leading products, accumulated in fp32 smallest first, give a dot product whose error against fp64 is that of
     a plain fp32 dot product (the three dropped products are below 2^-24 |a b|).
@@ -11,7 +12,7 @@ import torch
 
 
 def split3(a):
-    a0 = a.to(torch.bfloat16).float()
+    a0 = a.clamp(-3.3895313892515355e38, 3.3895313892515355e38).to(torch.bfloat16).float()      # split_pair's v_med3_f32 + cvt
     r1 = a - a0
     a1 = r1.to(torch.bfloat16).float()
     r2 = r1 - a1
@@ -23,7 +24,8 @@ def _samples(n, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, generator=g)
     scale = torch.exp2(torch.randint(-60, 60, (n,), generator=g).float())
-    edge = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 3.0e38, -3.0e38, 1.1754944e-38, 1e-40, 2.0 ** -149, 255.99998, 0.1])
+    edge = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 3.0e38, -3.0e38, 1.1754944e-38, 1e-40, 2.0 ** -149, 255.99998, 0.1,
+                         3.4028234e38, -3.4028234e38, 3.39e38, 3.3895e38])      # FLT_MAX and the values nearest-rounding would turn into inf
     return torch.cat([x, x * scale, edge])
 
 
@@ -36,8 +38,10 @@ def test_three_bf16_values_sum_to_the_fp32_value_exactly():
     s = a0.double() + a1.double() + a2.double()
     assert torch.equal(s[big], a.double()[big])                                     # exact, not merely to fp32 rounding
     assert ((s - a.double())[~big].abs() < 2.0 ** -126).all()
-    # the residuals shrink by 2^-8 per plane (round to nearest: half an ulp of an 8-bit significand)
-    nz = a != 0
+    assert torch.isfinite(a0).all() and torch.isfinite(a1).all() and torch.isfinite(a2).all()   # no plane overflows, FLT_MAX included
+    # the residuals shrink by 2^-8 per plane (round to nearest: half an ulp of an 8-bit significand); only the clamped values
+    # (beyond the largest bf16) leave up to one ulp
+    nz = (a != 0) & (a.abs() <= 3.3895313892515355e38)
     assert (a1[nz].abs() <= a[nz].abs() * 2.0 ** -8).all() and (a2[nz].abs() <= a[nz].abs() * 2.0 ** -16).all()
 
 

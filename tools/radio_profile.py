@@ -1,0 +1,47 @@
+"""BASELINE config 3 (radio 4 x 512 x 1024 + omic MaxNet B = 128 Cox) in a loop: target of rocprofv3 --kernel-trace --stats.
+usage: radio_profile.py [radio|omic|mm] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodalfusion_amd.models import MIL_Attention_fc_surv_radio, MaxNet, MM_MIL_Attention_fc_surv
+from multimodalfusion_amd.utils.loss_utils import CoxSurvLoss, NLLSurvLoss
+what = sys.argv[1] if len(sys.argv) > 1 else "radio"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+dev = torch.device("cuda", 0)
+torch.manual_seed(1)
+MODS = ["T1", "T2", "T1Gd", "FLAIR"]
+Y, c = torch.tensor([1], device=dev), torch.tensor([0.0], device=dev)
+nll, cox = NLLSurvLoss(alpha=0.0), CoxSurvLoss()
+if what == "radio":
+    model = MIL_Attention_fc_surv_radio(n_classes=4).to(dev).train()
+    kw = {m: torch.randn(512, 1024, device=dev) for m in MODS}
+    loss_of = lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)
+elif what == "omic":
+    model = MaxNet(input_dim=36, bag_loss="cox_surv").to(dev).train()
+    kw = {"genomic_features": torch.randn(128, 36, device=dev)}
+    ot = torch.rand(128, dtype=torch.float64) * 100
+    oc = (torch.rand(128, device=dev) < 0.5).float()
+    loss_of = lambda r: cox(risks=r[0], times=ot, c=oc)
+else:
+    model = MM_MIL_Attention_fc_surv(input_dim=80, fusion="concat", n_classes=4).to(dev).train()
+    kw = {m: torch.randn(512, 1024, device=dev) for m in MODS}
+    kw["path_features"] = torch.randn(50000, 1024, device=dev)
+    kw["genomic_features"] = torch.randn(80, device=dev)
+    loss_of = lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c)
+params = list(model.parameters())
+
+
+def step():
+    for p in params:
+        p.grad = None
+    loss_of(model(**kw)).backward()
+
+
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+print(f"{what}: {1e3 * (time.perf_counter() - t0) / steps:.4f} ms/step")
