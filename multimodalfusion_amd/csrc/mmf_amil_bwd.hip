@@ -1384,6 +1384,7 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   if (use_wide_tiles(p.N, p.H, p.split)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
+      case 48: return launch_bwd_dh_wide<48>(p, st);
       case 64: return launch_bwd_dh_wide<64>(p, st);
       case 128: return launch_bwd_dh_wide<128>(p, st);
       case 192: return launch_bwd_dh_wide<192>(p, st);

@@ -705,7 +705,7 @@ using TileW = Tile<ROWS, 256, 1, 8, true, true>;
 // 208 = six blocks + a 16-row half block (Tile::HALF): a 50k bag becomes 241 tiles on 241 CUs instead of 224
 int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
   static const int env = getenv("MMF_WIDE_ROWS") ? atoi(getenv("MMF_WIDE_ROWS")) : 0;   // tuning override
-  if (env > 0 && (env != 208 || allow_half)) return env;
+  if (env > 0 && ((env != 208 && env != 48) || allow_half)) return env;
   int best = 224;
   double bestc = 1e30;
   const int cand[5] = {224, 208, 192, 128, 64};   // 256 rows need > 256 VGPRs with double-buffered fragments (spills)
@@ -765,6 +765,7 @@ int launch_linear(LinearParams p, hipStream_t st) {
   }
   if (use_wide_tiles(p.M, p.N, can_split)) {
     switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0)) {
+      case 48: return launch_linear_wide<48>(p, st);
       case 64: return launch_linear_wide<64>(p, st);
       case 128: return launch_linear_wide<128>(p, st);
       case 192: return launch_linear_wide<192>(p, st);
