@@ -15,14 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmf_amil.so")
 OBJ = os.path.join(HERE, "_build")   # objects and -save-temps output (git- and gpurun-ignored)
-SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_amil_bf16_fwd2.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
+SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_amil_bf16_fwd2.hip", "mmf_amil_bf16_dh2.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
 HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_gemm_split.h", "mmf_gemm_dma.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h", "mmf_bf16.h",
            os.path.join("..", "..", "include", "mmf_amil.h")]
 # Per-file flags.  mmf_amil_bf16_fwd2.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_fma_f32 ...).  With
 # them the kernel (two 4-wave workgroups per CU, a wave's vector work beside its SIMD partner's MFMA stream) returned wrong
 # score partials in lanes 16-31 of the low register of a packed pair, a few tiles per launch, never with one workgroup per
 # CU (tools/f2_debug.py, tools/f2_debug2.py).  Packed fp32 is no gain beside MFMAs anyway (MI355X_MICROARCH.md).
-FILE_FLAGS = {"mmf_amil_bf16_fwd2.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"mmf_amil_bf16_fwd2.hip": ["-fno-slp-vectorize"], "mmf_amil_bf16_dh2.hip": ["-fno-slp-vectorize"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-result"] + os.environ.get("MMF_EXTRA_FLAGS", "").split()

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   if (s.transpose == 3) {
     const int kt = c >> 6, q = (c >> 4) & 3, hh = (c >> 3) & 1, w = r >> 6, fb = (r >> 5) & 1;
     s.dst[((size_t)((((kt * 4 + w) * 4 + q) * 2 + fb) * 64 + hh * 32 + (r & 31))) * 8 + (c & 7)] = v;
+  } else if (s.transpose == 5) {             // r = attention dim d, c = hidden feature f
+    const int kt = r >> 5, kk = s.c0 + (r & 31), q = kk >> 4, hh = (kk >> 3) & 1, w = c >> 6, fb = (c >> 5) & 1;
+    s.dst[((size_t)((((kt * 4 + w) * 4 + q) * 2 + fb) * 64 + hh * 32 + (c & 31))) * 8 + (kk & 7)] = v;
   } else if (s.transpose == 4) {
     const int ps = r >> 6, w = (r >> 4) & 3, sk = c >> 4, hh = (c >> 3) & 1;
     s.dst[((size_t)(((ps * 4 + w) * 16 + sk) * 64 + hh * 32 + s.c0 + (r & 15))) * 8 + (c & 7)] = v;

@@ -444,11 +444,12 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
   const bool fused2 = d->gated && fused_fwd2_ok(d->N, d->L, d->H, d->D);
   cvt(d->W1, w.w1, d->H, d->L, d->L, 0, fused2 ? 3 : 0);
   cvt(d->Wa, w.wab, d->D, d->H, d->H, 0, fused2 ? 4 : 0);
-  if (!infer) cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, d->gated ? 2 : 1);     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
+  const bool dh2 = !infer && dh2_bf16_ok(d->N, d->H, d->D, d->gated);         // K-dh's second form: [Wa ; Wb]^T in fragment order
+  if (!infer) cvt(d->Wa, w.wabT, d->D, d->H, w.mstk, 0, dh2 ? 5 : (d->gated ? 2 : 1));     // K-dh's k order (mmf_amil_bf16.hip: LoadPB)
   if (d->gated) {
     if (fused2) cvt(d->Wb, w.wab, d->D, d->H, d->H, 16, 4);
     else cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
-    if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, 2);
+    if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, dh2 ? 5 : 2);
   }
   if (fused2) { cp.zero = w.sched; cp.nzero = F2_SCHED_WORDS; }
   if (int e = launch_cvt_bf16(cp, st)) return e;
@@ -542,7 +543,9 @@ static int amil_bf16_backward_impl(const mmf_amil_desc* d, const uint16_t* x, vo
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
   dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
   dp.p_out = w.p; dp.ds_out = w.ds; dp.dbc_part = w.dbc_part; dp.dP = w.dP; dp.dwc_part = w.dwc_part;
-  if (int e = launch_dh_bf16(dp, st)) return e;
+  if (dh2_bf16_ok(d->N, d->H, d->D, d->gated)) {
+    if (int e = launch_dh2_bf16(dp, st)) return e;
+  } else if (int e = launch_dh_bf16(dp, st)) return e;
   const int ntn = d->H / 256;
 
   TnBfParams tp{};

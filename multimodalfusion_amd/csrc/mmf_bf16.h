@@ -42,6 +42,8 @@ struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  t
                            //   lane 32 hh + i, k-step q, row block fb, wave w, chunk kt at ((((kt 4 + w) 4 + q) 2 + fb) 64 + lane)
                            // transpose 4: Wa (c0 = 0) / Wb (c0 = 16) [256 x 256], unit of lane 32 hh + c0 + (d & 15), k-step s,
                            //   wave w = (d >> 4) & 3, pass ps = d >> 6 at (((ps 4 + w) 16 + s) 64 + lane)
+                           // transpose 5: Wa (c0 = 0) / Wb (c0 = 32) [256 x 256] as K-dh's A operand [feature][k'] in fragment order:
+                           //   k' = 64 (d / 32) + c0 + d % 32 (K-dh's chunk order), then as transpose 3 with L = 512
   const float* src; bf16_t* dst;
   int rows, cols, dst_ld, c0, transpose, block_begin;
 };
@@ -126,6 +128,8 @@ int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st);
 int dh_bf16_row_tiles(int64_t N);              // capacity of dbc_part (upper bound over tile choices)
 int dh_bf16_tiles_used(int64_t N, int ntn);     // dbc partials launch_dh_bf16 writes for this shape
 int launch_dh_bf16(DhBfParams p, hipStream_t st);
+bool dh2_bf16_ok(int64_t N, int H, int D, int gated);   // second form (mmf_amil_bf16_dh2.hip): WabT in A-fragment order (CvtSeg::transpose 5)
+int launch_dh2_bf16(DhBfParams p, hipStream_t st);
 int tn_bf16_splits(int64_t K, int total_tiles);
 int launch_tn_bf16(TnBfParams p, hipStream_t st);
 void debug_stamps_bf16(unsigned long long* out32);
