@@ -57,6 +57,37 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   float* dwc_l = wc_l + 256;                                       // [4][256]
   const unsigned act_bytes = (unsigned)p.N * 512u;                 // h, a, b, du rows are 512 bytes
 
+  // resources, per-thread offsets, and the first loads of the main loop (weights of chunk 0, a / b of chunks 0 and 1): issued
+  // before the prep so that their latency runs beside it (the registers are free: the accumulators do not exist yet)
+  const rsrc_t ra = make_rsrc(p.g.a, act_bytes), rbb = make_rsrc(p.g.b, act_bytes);
+  const rsrc_t rdp = make_rsrc(p.dP, (unsigned)p.N * 1024u);
+  const rsrc_t rw = make_rsrc(p.WabT, 256u * 512u * 2u);
+  const unsigned vw = (unsigned)lane * 16u + (unsigned)wave * 8192u;
+  const int piece = tid & 3, rl0 = tid >> 2;                       // builder: dims 8 piece .. + 7 of the chunk, rows rl0 and rl0 + 64
+  const uint32_t sd = p.g.seed_dev ? *p.g.seed_dev : 0u;
+  const uint32_t key_a = p.g.key_a + sd, key_b = p.g.key_b + sd;
+  const uint32_t thr = drop_threshold(p.g.drop_p);
+  const float dscale = p.g.drop_p > 0.f ? 1.0f / (1.0f - p.g.drop_p) : 1.0f;
+  unsigned vab[2], vdp[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rl = rl0 + 64 * j;
+    vab[j] = (unsigned)(row0 + rl) * 512u + 16u * (unsigned)piece;          // + 64 kt: the chunk's 32 dims
+    vdp[j] = (unsigned)(row0 + rl) * 1024u + 16u * (unsigned)piece;         // d pre-tanh at + 64 kt, d pre-sigmoid at + 512 + 64 kt
+  }
+  float4 wfr[8];                                                   // A fragments of the chunk in flight: [2 q + fb]
+  float4 la4[2][2], lb4[2][2];                                     // a, b of the next two chunks to be built: [chunk & 1][instance]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wfr[j] = bld4(rw, vw, (unsigned)(j * 1024));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    la4[0][j] = bld4(ra, vab[j], 0); lb4[0][j] = bld4(rbb, vab[j], 0);
+    la4[1][j] = bld4(ra, vab[j], 64); lb4[1][j] = bld4(rbb, vab[j], 64);
+  }
+
+  const float my_A = (tid < 128 && row0 + tid < p.N) ? p.A_raw[row0 + tid] : 0.f;
+  const float my_gA = (tid < 128 && row0 + tid < p.N && p.gA) ? p.gA[row0 + tid] : 0.f;
+
   // ---------------- prep: h tile -> LDS, g_i = dM . h_i, p_i, ds_i, relu' bits --------------------------------------------
   {
     const rsrc_t rh = make_rsrc(p.h, act_bytes);
@@ -100,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
       const int row = row0 + tid;
       float pi = 0.f, d = 0.f;
       if (row < p.N) {
-        pi = __expf(p.A_raw[row] - smax) * inv;
-        d = pi * (g_l[tid] - dmm) + (p.gA ? p.gA[row] : 0.f);
+        pi = __expf(my_A - smax) * inv;
+        d = pi * (g_l[tid] - dmm) + my_gA;
         p.p_out[row] = pi; p.ds_out[row] = d;
       }
       ds_l[tid] = d;
@@ -152,31 +183,8 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   }
 
   // ---------------- main loop ---------------------------------------------------------------------------------------------
-  const rsrc_t ra = make_rsrc(p.g.a, act_bytes), rbb = make_rsrc(p.g.b, act_bytes);
-  const rsrc_t rdp = make_rsrc(p.dP, (unsigned)p.N * 1024u);
-  const rsrc_t rw = make_rsrc(p.WabT, 256u * 512u * 2u);
-  const unsigned vw = (unsigned)lane * 16u + (unsigned)wave * 8192u;
-  const int piece = tid & 3, rl0 = tid >> 2;                       // builder: dims 8 piece .. + 7 of the chunk, rows rl0 and rl0 + 64
-  const uint32_t sd = p.g.seed_dev ? *p.g.seed_dev : 0u;
-  const uint32_t key_a = p.g.key_a + sd, key_b = p.g.key_b + sd;
-  const uint32_t thr = drop_threshold(p.g.drop_p);
-  const float dscale = p.g.drop_p > 0.f ? 1.0f / (1.0f - p.g.drop_p) : 1.0f;
   float dsv[2];
-  unsigned vab[2], vdp[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rl = rl0 + 64 * j;
-    dsv[j] = ds_l[rl];
-    vab[j] = (unsigned)(row0 + rl) * 512u + 16u * (unsigned)piece;          // + 64 kt: the chunk's 32 dims
-    vdp[j] = (unsigned)(row0 + rl) * 1024u + 16u * (unsigned)piece;         // d pre-tanh at + 64 kt, d pre-sigmoid at + 512 + 64 kt
-  }
-  float4 wfr[8];                                                   // A fragments of the chunk in flight: [2 q + fb]
-  float4 la4[2][2], lb4[2][2];                                     // a, b of the next two chunks to be built: [chunk & 1][instance]
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wfr[j] = bld4(rw, vw, (unsigned)(j * 1024));
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { la4[0][j] = bld4(ra, vab[j], 0); lb4[0][j] = bld4(rbb, vab[j], 0); }
-
+  dsv[0] = ds_l[rl0]; dsv[1] = ds_l[rl0 + 64];
   // The build of one chunk of the dP operand (from la4 / lb4: 2 instances x 8 dims per thread), cut into 16 SLICES of one
   // (instance, dim pair, dim) each -- ~15 vector instructions -- so that the chunk loop can put one slice behind every second
   // MFMA: a SIMD issues a wave's own vector instructions in the shadow of its MFMA (32 cycles), but hipcc emits independent
@@ -251,7 +259,6 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
     for (int j = 0; j < 2; ++j) { la[j] = bld4(ra, vab[j], (unsigned)(64 * kt)); lb[j] = bld4(rbb, vab[j], (unsigned)(64 * kt)); }
   };
 
-  load_ab(1, la4[1], lb4[1]);
   begin_build(0);
 #pragma unroll
   for (int s = 0; s < 16; ++s) slice(s, 0, lds + D2_IMG, la4[0], lb4[0]);

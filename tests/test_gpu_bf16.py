@@ -173,3 +173,31 @@ def test_mm_with_bf16_path_bag_tracks_the_fp32_run():
             continue
         err, nrm = float(np.linalg.norm(b["grads"][k] - g)), float(np.linalg.norm(g))
         assert err <= 0.15 * nrm + 1e-6, (k, err, nrm)
+
+
+@pytest.mark.parametrize("N", [100_000, 33_333])
+def test_bf16_step_is_bit_reproducible(N):
+    """Two 4-wave workgroups share a CU in the fused forward and in K-dh (second forms): any cross-wave race or missed hazard
+    shows as a handful of differing elements in a few tiles of a few launches (round 3 found one that way: packed-fp32
+    instructions in the fused forward, tools/f2_debug.py).  Scores and every gradient must be bit-identical over repeated
+    forward + backward passes (eval mode: no dropout seed involved)."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    torch.manual_seed(5)
+    model = MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=False, n_classes=4).to(DEV).eval()
+    x = torch.randn(N, 1024, device=DEV).to(torch.bfloat16)
+    Y, c = torch.tensor([1], device=DEV), torch.tensor([0.0], device=DEV)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        hz, S, Yh, A = model(path_features=x)
+        NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=Y, c=c).backward()
+        torch.cuda.synchronize()
+        return [A.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+
+    ref = step()
+    for i in range(10):
+        cur = step()
+        for k, (a, b) in enumerate(zip(cur, ref)):
+            assert torch.equal(a, b), (i, k, int((a != b).sum()))
