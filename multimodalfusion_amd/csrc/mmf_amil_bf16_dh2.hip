@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   float* dwc_l = wc_l + 256;                                       // [4][256]
   const unsigned act_bytes = (unsigned)p.N * 512u;                 // h, a, b, du rows are 512 bytes
 
-  // resources, per-thread offsets, and the first loads of the main loop (weights of chunk 0, a / b of chunks 0 and 1): issued
-  // before the prep so that their latency runs beside it (the registers are free: the accumulators do not exist yet)
+  // resources and per-thread offsets of the main loop
   const rsrc_t ra = make_rsrc(p.g.a, act_bytes), rbb = make_rsrc(p.g.b, act_bytes);
   const rsrc_t rdp = make_rsrc(p.dP, (unsigned)p.N * 1024u);
   const rsrc_t rw = make_rsrc(p.WabT, 256u * 512u * 2u);
@@ -77,14 +76,6 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   }
   float4 wfr[8];                                                   // A fragments of the chunk in flight: [2 q + fb]
   float4 la4[2][2], lb4[2][2];                                     // a, b of the next two chunks to be built: [chunk & 1][instance]
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wfr[j] = bld4(rw, vw, (unsigned)(j * 1024));
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    la4[0][j] = bld4(ra, vab[j], 0); lb4[0][j] = bld4(rbb, vab[j], 0);
-    la4[1][j] = bld4(ra, vab[j], 64); lb4[1][j] = bld4(rbb, vab[j], 64);
-  }
-
   const float my_A = (tid < 128 && row0 + tid < p.N) ? p.A_raw[row0 + tid] : 0.f;
   const float my_gA = (tid < 128 && row0 + tid < p.N && p.gA) ? p.gA[row0 + tid] : 0.f;
 
@@ -102,6 +93,15 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
       *reinterpret_cast<float4*>(lds + D2_IMG + R * 512 + 16 * (s ^ (R & 15))) = hv[i];
     }
   }
+  // the main loop's first operands: requested now (the 64 registers of the h tile are free again), landing beside the prep
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wfr[j] = bld4(rw, vw, (unsigned)(j * 1024));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    la4[0][j] = bld4(ra, vab[j], 0); lb4[0][j] = bld4(rbb, vab[j], 0);
+    la4[1][j] = bld4(ra, vab[j], 64); lb4[1][j] = bld4(rbb, vab[j], 64);
+  }
+
   float dmm = 0.f;                                                 // dM . M
   dmm = p.dM[lane] * p.Mpool[lane] + p.dM[lane + 64] * p.Mpool[lane + 64] + p.dM[lane + 128] * p.Mpool[lane + 128]
       + p.dM[lane + 192] * p.Mpool[lane + 192];
@@ -159,7 +159,11 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
               | ((w2.y & 0xFFFFu) ? 1u : 0u) << (4 * g + 2) | ((w2.y >> 16) ? 1u : 0u) << (4 * g + 3);
       }
       rb[2 * fb + (ib >> 1)] |= bits << (16 * (ib & 1));
+      asm volatile("" ::: "memory");                               // one block's four reads at a time (all 32 at once spill 64 registers)
     }
+  // the bits are wanted HERE, as four registers: left alone the compiler keeps the 64 raw dwords (in scratch: +200 MB of HBM
+  // traffic per launch at 100k) and extracts the bits in the epilogue
+  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
   __syncthreads();                                                 // ds / p complete; every read of the h image done
   if (tid == 0) p.dbc_part[mt] = red[0] + red[1] + red[2] + red[3];
 

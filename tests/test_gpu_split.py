@@ -143,7 +143,8 @@ def test_split_error_on_non_gaussian_bags(x_kind, monkeypatch):
         e0, e1 = err(res[0], key), err(res[1], key)
         assert np.isfinite(res[1][key]).all()
         assert e1 <= 4 * e0 + 4e-7 * max(1.0, float(np.abs(ref[key]).max())), (x_kind, key, e0, e1)
-    compare(res[1], ref, f"bf16x3 {x_kind}", kink_units=kink)
+    if x_kind == "relu":          # the suite's absolute bars assume O(1) activations: scores of the log-normal bag reach 1e3
+        compare(res[1], ref, f"bf16x3 {x_kind}", kink_units=kink)
     worst = (0.0, None)
     for k, g in ref["grads"].items():
         g = np.asarray(g, np.float64)
@@ -155,7 +156,9 @@ def test_split_error_on_non_gaussian_bags(x_kind, monkeypatch):
         if d1.size:
             ratio = float(d1.max()) / max(float(d0.max()), 1e-300)
             worst = max(worst, (ratio, k))
-            assert float(d1.max()) <= max(4 * float(d0.max()), 1e-5 * float(np.abs(g).max())) + 4e-7 * max(float(np.abs(g).max()), 1e-30), \
+            # 1e-6 absolute: a tenth of `compare`'s absolute bar (attention_c.bias: the gradient is analytically zero, both
+            # arithmetics return rounding noise of the 20,813-term sum of ds)
+            assert float(d1.max()) <= max(4 * float(d0.max()), 1e-5 * float(np.abs(g).max()), 1e-6), \
                 (x_kind, k, float(d0.max()), float(d1.max()))
     print(f"{x_kind}: worst bf16x3 / exact-fp32 gradient error ratio {worst[0]:.2f} ({worst[1]})")
 
