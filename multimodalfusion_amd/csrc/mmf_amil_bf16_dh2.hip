@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   chunk(7, std::false_type{}, la4[0], lb4[0], la4[1], lb4[1]);
 
   // ---------------- epilogue: du = relu' ? acc . scale_h : 0 -> LDS du image -> whole rows to HBM -----------------------------
+  // (addresses from a thread index the compiler cannot see through, or it computes them at the top and parks them in scratch)
+  int tid_late = threadIdx.x;
+  asm volatile("" : "+v"(tid_late));
+  {
+  const int tid = tid_late, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   {
     const float sh = p.scale_h;
 #pragma unroll
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
   }
   // per-tile dWc partial: the four waves' row sums
   p.dwc_part[(size_t)mt * 256 + tid] = dwc_l[tid] + dwc_l[256 + tid] + dwc_l[512 + tid] + dwc_l[768 + tid];
+  }
 }
 
 bool dh2_bf16_ok(int64_t N, int H, int D, int gated) {

@@ -114,6 +114,7 @@ __device__ inline void f2_chunk(const char* xs, const f32x4v (&wf)[8], f32x16 (&
   }
 }
 
+template <bool HLOOP>      // projection dropout on and L == 1024: the keep-bits are hashed inside the main loop
 __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdParams p) {
   extern __shared__ __align__(16) char lds2[];
   char* lds = lds2;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     asm volatile("" :: "v"(bias[0]), "v"(bias[4]), "v"(bias[8]), "v"(bias[12]));   // the compiler's own waits for these loads stay in front of the hidden queue
   }
   const uint32_t thr_h = drop_threshold(p.p_h);
-  const bool hloop = p.p_h > 0.f && p.L == 1024 && p.hash_in_loop;   // 16 chunks: keep-bits hashed inside the main loop
+  constexpr bool hloop = HLOOP;
   const uint32_t hbase = ((uint32_t)(row0 + r) * 256u + 64u * (uint32_t)wave + 4u * (uint32_t)hh) * 0x9E3779B1u + p.key_h + sdev;
   uint32_t km[4] = {0u, 0u, 0u, 0u};                              // bit e = ((fb 4 + ib) 4 + g) 4 + j of word e / 32: keep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the hand-counted queue below starts empty
@@ -194,8 +195,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     // The dropout keep-bits of the projection (model_attention_mil_path.py:21) depend on indices only: with 16 chunks they
     // are hashed here, 8 elements per chunk between the MFMAs (the loop waits for memory, its vector ALU is idle), and the
     // epilogue only applies them.  Element e = ((fb 4 + ib) 4 + g) 4 + j of this lane is hashed in chunk e / 8.
-    auto main_loop = [&](auto hl_c) {
-      constexpr bool HLOOP = decltype(hl_c)::value;
+    {
       auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
         if (!(dbg & 2)) load_w(kt + 1, wnext);
         if (!(dbg & 1)) lx.issue(kt + 2, stage(kt + 2));
@@ -232,14 +232,19 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
         iter(kt, wf0, wf1);
         iter(kt + 1, wf1, wf0);
       }
-    };
-    if (hloop) main_loop(std::true_type{}); else main_loop(std::false_type{});
+    }
     wait_vmcnt<0>();                                             // the two refills past the last chunk
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
 
   B2_MARK(0);
+  // Everything below derives its lane-dependent addresses from a thread index the compiler cannot see through: left alone it
+  // computes the epilogues' LDS / store offsets at the top of the kernel and parks them in scratch across the main loop.
+  int tid_late = threadIdx.x;
+  asm volatile("" : "+v"(tid_late));
+  {
+  const int tid = tid_late, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   // ---------------- epilogue 1: h = bf16(drop(relu(u))) -> the LDS h image (B operand of phase 2, pooled operand) ----
   {
     const float scale = p.p_h > 0.f ? 1.0f / (1.0f - p.p_h) : 1.0f;
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     out[2 + tid] = s;
   }
   if (tid == 0) { out[0] = m; out[1] = red[8] + red[9]; }
+  }
   B2_MARK(3);
   B2_COUNT();
 }
@@ -484,7 +490,8 @@ int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st) {
   static const int hl = getenv("MMF_F2_HLOOP") ? atoi(getenv("MMF_F2_HLOOP")) : 1;       // A/B switch
   p.stagger = dbg;
   p.hash_in_loop = hl;
-  auto kern = amil_fwd_fused2_bf16_kernel;
+  const bool hloop = p.p_h > 0.f && p.L == 1024 && p.hash_in_loop;
+  auto kern = hloop ? amil_fwd_fused2_bf16_kernel<true> : amil_fwd_fused2_bf16_kernel<false>;
   static const int lds_env = getenv("MMF_F2_LDS") ? atoi(getenv("MMF_F2_LDS")) : 0;     // experiment: > 80 KB forces one workgroup per CU
 #ifdef MMF_F2_REV_GPAR
   const int lds_bytes = lds_env > 0 ? lds_env : F2_LDS_BYTES;       // experiment: any size (the gate parameters are not in LDS)
