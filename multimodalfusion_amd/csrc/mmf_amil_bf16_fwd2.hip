@@ -285,140 +285,154 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
   __syncthreads();                                         // h tile complete
   B2_MARK(1);
   // saved activations go out through buffer stores: rows beyond the bag fall outside num_records and are dropped
+  // (forward-only calls: zero-size resources drop every store, so that no phase below needs a branch)
   const unsigned act_bytes = (unsigned)p.N * 512u;
-  if (p.h && !(dbg & 128)) {                               // whole 512-byte rows per wave instruction
-    const rsrc_t rh = make_rsrc(p.h, act_bytes);
-    const int s = tid & 31;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int R = 8 * i + (tid >> 5);
-      const float4 v = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (s ^ (R & 15)));
-      bst4(rh, (unsigned)(row0 + R) * 512u + 16u * (unsigned)s, v);
-    }
-  }
-  const rsrc_t rsa = make_rsrc(p.a ? p.a : p.h, p.a ? act_bytes : 0u), rsb = make_rsrc(p.a ? p.b : p.h, p.a ? act_bytes : 0u);
+  const bool keep_h = p.h && !(dbg & 128);
+  const rsrc_t rh = make_rsrc(keep_h ? (const void*)p.h : (const void*)p.x, keep_h ? act_bytes : 0u);
+  const rsrc_t rsa = make_rsrc(p.a ? (const void*)p.a : (const void*)p.x, p.a ? act_bytes : 0u),
+               rsb = make_rsrc(p.a ? (const void*)p.b : (const void*)p.x, p.a ? act_bytes : 0u);
 
   // ---------------- phase 2: [a ; b]^T = (gate weights) . h^T as a software pipeline -------------------------------------
   // 16 blocks (pass ps = 0..3: attention dims 64 ps + 16 w .. + 15; instance block ib = 0..3).  A block is ONE 32 x 32
   // accumulator: 16 MFMAs along K = 256 (rows 0-15 of the A block are Wa, rows 16-31 Wb of the same dims: accumulator
-  // i < 8 is pre-tanh, i >= 8 pre-sigmoid of dim dbase + 8 ((i >> 2) & 1) + 4 hh + (i & 3)), then ~150 vector
-  // instructions: tanh / sigmoid, bf16 rounding, a / b stores (16 contiguous bytes per lane after the half swap), score
-  // partial.  A SIMD does not run one wave's vector work beside its partner's dense MFMA stream (tools/coissue.hip), but
-  // it does issue a wave's OWN vector instructions in the shadow of that wave's MFMAs: so the MFMAs of block k are issued
-  // in the same region as the activations of block k - 1 (accumulators alternate), and the weights of the next pass
-  // (second register set) arrive while this pass multiplies.
+  // i < 8 is pre-tanh, i >= 8 pre-sigmoid of dim dbase + 8 ((i >> 2) & 1) + 4 hh + (i & 3)), then its activations:
+  // 32 quarter-rate instructions (exp2, rcp) and ~120 others -- tanh / sigmoid, bf16 rounding, a / b stores (16
+  // contiguous bytes per lane after the half swap), score partial: about twice the block's MFMA time.  A SIMD does not run
+  // one wave's vector work beside its partner's dense MFMA stream (tools/coissue.hip), but it does issue a wave's OWN
+  // vector instructions in the shadow of that wave's MFMAs.  So block k's 16 (dependent) MFMAs are issued one by one
+  // with ONE SLICE of block k - 1's activations behind each -- one activation of one accumulator element per slice, the
+  // slices pinned in place (sched_barrier): left to itself the scheduler bunched the vector work into runs of 150-300
+  // instructions with the matrix pipe idle.  The accumulators alternate; the weights of the next pass (second register
+  // set) arrive four k-steps per block.  Block 0 has no predecessor: the h copy-out rides behind its MFMAs instead, and
+  // a 17th, empty block (its weights read as zero beyond the buffer) carries block 15's activations.
   const uint32_t thr_a = drop_threshold(p.p_att);
   const bool drop = p.p_att > 0.f;
   const float dscale = drop ? 1.0f / (1.0f - p.p_att) : 1.0f;
   const uint32_t key_a = p.key_a + sdev, key_b = p.key_b + sdev;
   float sc[4] = {0.f, 0.f, 0.f, 0.f};                      // score partials of instance 32 ib + r over this lane's dims
-  const char* hb0 = lds + F2_HIMG + r * 512;
-  const int sx = r & 15;
   auto gate_phase = [&](auto drop_c) {                     // attention dropout on / off decided once, not per element
     constexpr bool DROP = decltype(drop_c)::value;
     f32x16 ag0, ag1;                                       // accumulators of the even / odd instance blocks
-    // MFMAs of block (dbase, ib) into `acc`, which starts as the biases (read from LDS straight into the accumulator)
-    auto mm = [&](const float4 (&w)[16], f32x16& acc, int dbase, int ib) {
+    // an accumulator starts as the biases of its block's dims (read from LDS straight into the accumulator)
+    auto bias_init = [&](f32x16& acc, const float* gb) {    // gb = gpar + 4 hh + (first dim of the block)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const float4 ta = ld4(gpar + dbase + 8 * g + 4 * hh), tb = ld4(gpar + 256 + dbase + 8 * g + 4 * hh);
+        const float4 ta = ld4(gb + 8 * g), tb = ld4(gb + 256 + 8 * g);
         acc[4 * g] = ta.x; acc[4 * g + 1] = ta.y; acc[4 * g + 2] = ta.z; acc[4 * g + 3] = ta.w;
         acc[8 + 4 * g] = tb.x; acc[8 + 4 * g + 1] = tb.y; acc[8 + 4 * g + 2] = tb.z; acc[8 + 4 * g + 3] = tb.w;
       }
-      float4 fh[2];
-      const char* hb = hb0 + ib * 32 * 512;
-      fh[0] = *reinterpret_cast<const float4*>(hb + 16 * ((0 + hh) ^ sx));
+    };
+    // One block.  MFMAs: block (dbM, ibM) into accM with the weights w.  Slices: the activations of block (dbA, ibA)
+    // from accA (MODE 1) or the h copy-out (MODE 0).  Four k-steps of the next pass's weights (offset nw) go into
+    // wn[4 slot ..]; at the end accA becomes the biases of the block it accumulates next (dims dbN ..).
+    // The h fragments (B operands) come from LDS through a ring of four, three k-steps ahead and across block ends (ibN =
+    // instance block of the next block): one step ahead, every MFMA waited out an LDS round trip.
+    float4 fh[4];
+    auto blk = [&](auto mode_c, const float4 (&w)[16], f32x16& accM, int ibM, int ibN, f32x16& accA, int dbA, int ibA,
+                   float4 (&wn)[16], int slot, unsigned nw, int dbN) {
+      constexpr int MODE = decltype(mode_c)::value;
+      // lane-derived addresses are rebuilt per block from laundered lane coordinates: hoisted out of the round loop
+      // they would be parked in scratch (64 fragment addresses alone)
+      int rl = r, hl = hh;
+      asm volatile("" : "+v"(rl), "+v"(hl));
+      const char* hb = lds + F2_HIMG + ibM * 32 * 512;
+      const char* hbn = lds + F2_HIMG + ibN * 32 * 512;
+      const unsigned a0 = (unsigned)rl * 512u + 16u * (unsigned)(hl ^ (rl & 15));   // slot (2 s + hh) ^ sx = (hh ^ sx) ^ 2 s
+      const int row = row0 + 32 * ibA + rl;
+      const float* gp = gpar + 4 * hl;
+      float wc[8], av[2], bv[2];
+      uint32_t pa[4], pb[4];                               // [2 g + (0: dims 0-1, 1: dims 2-3 of the group)]
+      bool ka[2], kb[2];
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) fh[s] = *reinterpret_cast<const float4*>(hb + (a0 ^ (unsigned)(32 * s)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        if (s + 1 < 16) fh[(s + 1) & 1] = *reinterpret_cast<const float4*>(hb + 16 * ((2 * (s + 1) + hh) ^ sx));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(w[s]), frag_of(fh[s & 1]), acc, 0, 0, 0);
-      }
-    };
-    // activations of block (dbase, ib) from `acc`
-    auto act = [&](const f32x16& acc, int dbase, int ib) {
-      if (dbg & 16) { sc[ib] += acc[0] + acc[15]; return; }
-      float wc[8];
+        fh[(s + 3) & 3] = *reinterpret_cast<const float4*>((s + 3 < 16 ? hb : hbn) + (a0 ^ (unsigned)(32 * ((s + 3) & 15))));
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(w[s]), frag_of(fh[s & 3]), accM, 0, 0, 0);
+        if constexpr (MODE == 0) {                         // whole 512-byte rows of h per wave instruction
+          const int R = 8 * s + (tid >> 5), c = tid & 31;
+          const float4 v = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (c ^ (R & 15)));
+          bst4(rh, (unsigned)(row0 + R) * 512u + 16u * (unsigned)c, v);
+        } else if (dbg & 16) {
+          if (s == 0) sc[ibA] += accA[0] + accA[15];
+        } else {
+          // slice s: one activation.  g = s >> 3 (dims 8 g ..), j = (s >> 1) & 3, even s: tanh, odd s: sigmoid
+          const int g = s >> 3, j = (s >> 1) & 3, e = j & 1;
+          if (s == 0) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const float4 tw = ld4(gpar + 512 + dbase + 8 * g + 4 * hh);
-        wc[4 * g] = tw.x; wc[4 * g + 1] = tw.y; wc[4 * g + 2] = tw.z; wc[4 * g + 3] = tw.w;
-      }
-      const int R = 32 * ib + r, row = row0 + R;
-      uint32_t pa[4], pb[4];                               // [2 g + (0: dims 0-1, 1: dims 2-3 of the group)]
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          av[j] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[4 * g + j] * -2.885390082f)), -1.0f);   // tanh
-          bv[j] = fast_sigmoid(acc[8 + 4 * g + j]);
-        }
-        pa[2 * g] = pack2(av[0], av[1]); pa[2 * g + 1] = pack2(av[2], av[3]);
-        pb[2 * g] = pack2(bv[0], bv[1]); pb[2 * g + 1] = pack2(bv[2], bv[3]);
-        // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
-        unpack2(pa[2 * g], av[0], av[1]); unpack2(pa[2 * g + 1], av[2], av[3]);
-        unpack2(pb[2 * g], bv[0], bv[1]); unpack2(pb[2 * g + 1], bv[2], bv[3]);
-        const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(dbase + 8 * g + 4 * hh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float ad = av[j], bd = bv[j];
-          if constexpr (DROP) {
-            ad = keep(key_a, idx + j, thr_a) ? ad * dscale : 0.f;
-            bd = keep(key_b, idx + j, thr_a) ? bd * dscale : 0.f;
+            for (int g2 = 0; g2 < 2; ++g2) {
+              const float4 tw = ld4(gp + 512 + dbA + 8 * g2);
+              wc[4 * g2] = tw.x; wc[4 * g2 + 1] = tw.y; wc[4 * g2 + 2] = tw.z; wc[4 * g2 + 3] = tw.w;
+            }
           }
-          sc[ib] = __builtin_fmaf(ad * bd, wc[4 * g + j], sc[ib]);   // spelled out: the same two roundings for every block and lane
+          const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(dbA + 8 * g + 4 * hl + j);
+          if ((s & 1) == 0) {
+            av[e] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accA[4 * g + j] * -2.885390082f)), -1.0f);   // tanh
+            if constexpr (DROP) ka[e] = keep(key_a, idx, thr_a);
+          } else {
+            bv[e] = fast_sigmoid(accA[8 + 4 * g + j]);
+            if constexpr (DROP) kb[e] = keep(key_b, idx, thr_a);
+            if (e == 1) {
+              pa[2 * g + (j >> 1)] = pack2(av[0], av[1]);
+              pb[2 * g + (j >> 1)] = pack2(bv[0], bv[1]);
+              // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
+              unpack2(pa[2 * g + (j >> 1)], av[0], av[1]);
+              unpack2(pb[2 * g + (j >> 1)], bv[0], bv[1]);
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                float ad = av[q], bd = bv[q];
+                if constexpr (DROP) {
+                  ad = ka[q] ? ad * dscale : 0.f;
+                  bd = kb[q] ? bd * dscale : 0.f;
+                }
+                sc[ibA] = __builtin_fmaf(ad * bd, wc[4 * g + j - 1 + q], sc[ibA]);   // spelled out: the same two roundings for every block and lane
+              }
+            }
+          }
+          if (s == 15) {
+            // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
+            // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
+            uint32_t oa[4], ob[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              auto sa = __builtin_amdgcn_permlane32_swap(pa[q], pa[2 + q], false, false);
+              auto sb = __builtin_amdgcn_permlane32_swap(pb[q], pb[2 + q], false, false);
+              oa[q] = sa[0]; oa[2 + q] = sa[1];
+              ob[q] = sb[0]; ob[2 + q] = sb[1];
+            }
+            const unsigned o = (unsigned)row * 512u + (unsigned)(dbA + 8 * hl) * 2u;
+            bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
+            bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
+          }
         }
+        if (s >= 8 && s < 12) wn[4 * slot + s - 8] = bld4(rg, vg, nw + (unsigned)((4 * slot + s - 8) * 1024));
+        if (s == 15) bias_init(accA, gp + dbN);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      {   // no branch (forward-only calls: zero-size resources drop the stores): one scheduling region per block
-        // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
-        // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
-        uint32_t oa[4], ob[4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          auto sa = __builtin_amdgcn_permlane32_swap(pa[q], pa[2 + q], false, false);
-          auto sb = __builtin_amdgcn_permlane32_swap(pb[q], pb[2 + q], false, false);
-          oa[q] = sa[0]; oa[2 + q] = sa[1];
-          ob[q] = sb[0]; ob[2 + q] = sb[1];
-        }
-        const unsigned o = (unsigned)row * 512u + (unsigned)(dbase + 8 * hh) * 2u;
-        bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
-        bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
-      }
-    };
-    // one pass: its four blocks multiply while the previous block's activations are taken and the next pass's weights load
-    auto pass = [&](int ps, const float4 (&w)[16], float4 (&wn)[16]) {
-      const int dbase = 64 * ps + 16 * wave;
-      asm volatile("" ::: "memory");                       // gate parameters and h fragments are re-read every pass
-      const unsigned nw = __builtin_amdgcn_readfirstlane((unsigned)(ps + 1) * 65536u);   // pass 4 does not exist: reads as zero
-      __builtin_amdgcn_sched_barrier(0);
-      mm(w, ag0, dbase, 0);
-      if (ps > 0) act(ag1, dbase - 64, 3);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
-      __builtin_amdgcn_sched_barrier(0);
-      mm(w, ag1, dbase, 1);
-      act(ag0, dbase, 0);
-#pragma unroll
-      for (int s = 4; s < 8; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
-      __builtin_amdgcn_sched_barrier(0);
-      mm(w, ag0, dbase, 2);
-      act(ag1, dbase, 1);
-#pragma unroll
-      for (int s = 8; s < 12; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
-      __builtin_amdgcn_sched_barrier(0);
-      mm(w, ag1, dbase, 3);
-      act(ag0, dbase, 2);
-#pragma unroll
-      for (int s = 12; s < 16; ++s) wn[s] = bld4(rg, vg, nw + (unsigned)(s * 1024));
-      __builtin_amdgcn_sched_barrier(0);
     };
     if (!(dbg & 8)) {
+      constexpr std::integral_constant<int, 0> copy_h{};
+      constexpr std::integral_constant<int, 1> acts{};
+      const int d0 = 16 * wave;
+      bias_init(ag0, gpar + 4 * hh + d0);
+      blk(copy_h, wg0, ag0, 0, 1, ag1, 0, 0, wg1, 0, 65536u, d0);          // block (0, 0); ag1 then accumulates block (0, 1)
 #pragma unroll 1
       for (int p2 = 0; p2 < 2; ++p2) {
-        pass(2 * p2, wg0, wg1);
-        pass(2 * p2 + 1, wg1, wg0);
+        asm volatile("" ::: "memory");                     // gate parameters and h fragments are re-read every round
+        const int db = 128 * p2 + d0;                      // passes ps = 2 p2 (weights wg0) and ps + 1 (wg1)
+        const unsigned n1 = __builtin_amdgcn_readfirstlane((unsigned)(2 * p2 + 1) * 65536u);   // passes 4, 5 do not exist: read as zero
+        blk(acts, wg0, ag1, 1, 2, ag0, db, 0, wg1, 1, n1, db);
+        blk(acts, wg0, ag0, 2, 3, ag1, db, 1, wg1, 2, n1, db);
+        blk(acts, wg0, ag1, 3, 0, ag0, db, 2, wg1, 3, n1, db + 64);
+        blk(acts, wg1, ag0, 0, 1, ag1, db, 3, wg0, 0, n1 + 65536u, db + 64);
+        blk(acts, wg1, ag1, 1, 2, ag0, db + 64, 0, wg0, 1, n1 + 65536u, db + 64);
+        blk(acts, wg1, ag0, 2, 3, ag1, db + 64, 1, wg0, 2, n1 + 65536u, db + 64);
+        blk(acts, wg1, ag1, 3, 0, ag0, db + 64, 2, wg0, 3, n1 + 65536u, db + 128);
+        blk(acts, wg0, ag0, 0, 1, ag1, db + 64, 3, wg1, 0, n1 + 131072u, db + 128);   // p2 = 1: the empty 17th block
       }
-      act(ag1, 192 + 16 * wave, 3);
     }
   };
   if (drop) gate_phase(std::true_type{}); else gate_phase(std::false_type{});

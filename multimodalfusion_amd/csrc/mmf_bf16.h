@@ -19,7 +19,12 @@ __device__ inline bf16_t f2bf(float f) {            // round to nearest even (v_
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(bf16_t, h);
 }
-__device__ inline uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef float f32pair __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16pair __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pack2(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (the scalar form costs two and an OR)
+  const f32pair v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16pair));
+}
 __device__ inline void unpack2(uint32_t w, float& lo, float& hi) {
   lo = __uint_as_float(w << 16);
   hi = __uint_as_float(w & 0xFFFF0000u);
