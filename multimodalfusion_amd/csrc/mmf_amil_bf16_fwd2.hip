@@ -22,8 +22,8 @@
 //     refilled k-step by k-step for the next pass right behind the MFMA that used them.
 //
 // LDS map (bytes): [0, 49152) three x stages of [128 rows][128 B] (XOR-swizzled as mmf_gemm_dma.h), later
-//                  [0, 65536) h image [128 rows][512 B], 16-byte slots XOR-swizzled with (row & 15);
-//                  [65536, ...) score partials [4 waves][128], e[128], scratch[16], pooling partials [8][256], ba / bb / Wc [3][256].
+//                  [0, 67584) h image [128 rows][528 B] (512 B of features + 16 B of padding);
+//                  [67584, ...) score partials [4 waves][128], e[128], scratch[16], pooling partials [8][256], ba / bb / Wc [3][256].
 // Reference lines: models/model_attention_mil_path.py:52-56 (projection, attention net, softmax pooling),
 // models/model_modules.py:105-110 (Attn_Net_Gated.forward).
 #include <type_traits>
@@ -36,7 +36,10 @@ namespace mmf {
 
 constexpr int F2_BM = 128;
 constexpr int F2_STAGE = F2_BM * 128;                 // one x chunk: 128 rows x 64 bf16
-constexpr int F2_HIMG = 0, F2_MISC = 65536;
+constexpr int F2_HROW = 528;                          // h image row pitch: 512 B + 16 (pitch / 4 = 4 mod 64 banks: the 16 lanes of a
+                                                      // ds_read_b128 group, one row each, cover all 64 banks with NO address swizzle,
+                                                      // so a k-step is an immediate offset of the read, not an instruction)
+constexpr int F2_HIMG = 0, F2_MISC = F2_BM * F2_HROW;
 constexpr int F2_LDS_BYTES = F2_MISC + (4 * 128 + 128 + 16 + 8 * 256 + 3 * 256) * 4;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
           const int R = 32 * ib + r;
-          char* rowp = lds + F2_HIMG + R * 512 + 8 * hh;
+          char* rowp = lds + F2_HIMG + R * F2_HROW + 8 * hh;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int f = 64 * wave + 32 * fb + 8 * g + 4 * hh;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
               if constexpr (MODE == 2) y[j] = keep(dkey, (uint32_t)(row0 + R) * 256u + (uint32_t)(f + j), thr_h) ? y[j] * scale : 0.f;
             }
             const int slot = 8 * wave + 4 * fb + g;
-            *reinterpret_cast<uint2*>(rowp + 16 * (slot ^ (R & 15))) = pack4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<uint2*>(rowp + 16 * slot) = pack4(y[0], y[1], y[2], y[3]);
           }
         }
     };
@@ -335,32 +338,43 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
       // they would be parked in scratch (64 fragment addresses alone)
       int rl = r, hl = hh;
       asm volatile("" : "+v"(rl), "+v"(hl));
-      const char* hb = lds + F2_HIMG + ibM * 32 * 512;
-      const char* hbn = lds + F2_HIMG + ibN * 32 * 512;
-      const unsigned a0 = (unsigned)rl * 512u + 16u * (unsigned)(hl ^ (rl & 15));   // slot (2 s + hh) ^ sx = (hh ^ sx) ^ 2 s
+      const char* hb = lds + F2_HIMG + (rl * F2_HROW + 16 * hl);                   // + (32 ib) rows + 32 s bytes: immediates
       const int row = row0 + 32 * ibA + rl;
       const float* gp = gpar + 4 * hl;
-      float wc[8], av[2], bv[2];
+      float wc[8], te[16];
       uint32_t pa[4], pb[4];                               // [2 g + (0: dims 0-1, 1: dims 2-3 of the group)]
-      bool ka[2], kb[2];
+      bool kp[16];
       if constexpr (MODE == 0) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) fh[s] = *reinterpret_cast<const float4*>(hb + (a0 ^ (unsigned)(32 * s)));
+        for (int s = 0; s < 3; ++s) fh[s] = *reinterpret_cast<const float4*>(hb + ibM * 32 * F2_HROW + 32 * s);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        fh[(s + 3) & 3] = *reinterpret_cast<const float4*>((s + 3 < 16 ? hb : hbn) + (a0 ^ (unsigned)(32 * ((s + 3) & 15))));
+        fh[(s + 3) & 3] = *reinterpret_cast<const float4*>(hb + (s + 3 < 16 ? ibM : ibN) * 32 * F2_HROW + 32 * ((s + 3) & 15));
+#ifndef MMF_F2_GATE_NOMM      /* diagnostic builds (wrong results): the gate phase without its MFMAs / without its activations */
         accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_of(w[s]), frag_of(fh[s & 3]), accM, 0, 0, 0);
+#else
+        asm volatile("" :: "v"(w[s].x), "v"(fh[s & 3].x));
+#endif
+#ifdef MMF_F2_GATE_NOACT
+        if (MODE == 1) { if (s == 0) sc[ibA] += accA[0] + accA[15]; } else
+#endif
         if constexpr (MODE == 0) {                         // whole 512-byte rows of h per wave instruction
           const int R = 8 * s + (tid >> 5), c = tid & 31;
-          const float4 v = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (c ^ (R & 15)));
+          const float4 v = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * F2_HROW + 16 * c);
+#ifndef MMF_F2_NOHSTORE
           bst4(rh, (unsigned)(row0 + R) * 512u + 16u * (unsigned)c, v);
+#else
+          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
         } else if (dbg & 16) {
           if (s == 0) sc[ibA] += accA[0] + accA[15];
         } else {
-          // slice s: one activation.  g = s >> 3 (dims 8 g ..), j = (s >> 1) & 3, even s: tanh, odd s: sigmoid
-          const int g = s >> 3, j = (s >> 1) & 3, e = j & 1;
+          // Element e = 0..15 of the block: g = e >> 3 (dims 8 g ..), j = (e >> 1) & 3, even e: tanh of accA[4 g + j], odd e:
+          // sigmoid of accA[8 + 4 g + j].  An activation is a dependent chain (scale, exp2, 1 +, rcp, [2 x - 1]) of long-latency
+          // instructions, so it runs as a three-stage pipeline ACROSS slices: slice s takes stage A of element s, stage B
+          // of element s - 1 and stage C of element s - 2 -- three independent chains per slice; slice 15 drains.
           if (s == 0) {
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
@@ -368,30 +382,38 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
               wc[4 * g2] = tw.x; wc[4 * g2 + 1] = tw.y; wc[4 * g2 + 2] = tw.z; wc[4 * g2 + 3] = tw.w;
             }
           }
-          const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(dbA + 8 * g + 4 * hl + j);
-          if ((s & 1) == 0) {
-            av[e] = __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(accA[4 * g + j] * -2.885390082f)), -1.0f);   // tanh
-            if constexpr (DROP) ka[e] = keep(key_a, idx, thr_a);
-          } else {
-            bv[e] = fast_sigmoid(accA[8 + 4 * g + j]);
-            if constexpr (DROP) kb[e] = keep(key_b, idx, thr_a);
-            if (e == 1) {
-              pa[2 * g + (j >> 1)] = pack2(av[0], av[1]);
-              pb[2 * g + (j >> 1)] = pack2(bv[0], bv[1]);
-              // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
-              unpack2(pa[2 * g + (j >> 1)], av[0], av[1]);
-              unpack2(pb[2 * g + (j >> 1)], bv[0], bv[1]);
-#pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                float ad = av[q], bd = bv[q];
-                if constexpr (DROP) {
-                  ad = ka[q] ? ad * dscale : 0.f;
-                  bd = kb[q] ? bd * dscale : 0.f;
-                }
-                sc[ibA] = __builtin_fmaf(ad * bd, wc[4 * g + j - 1 + q], sc[ibA]);   // spelled out: the same two roundings for every block and lane
-              }
+          auto stA = [&](int e) {                            // exp2 of the scaled pre-activation
+            const int g = e >> 3, j = (e >> 1) & 3;
+            te[e] = (e & 1) ? __builtin_amdgcn_exp2f(accA[8 + 4 * g + j] * -1.442695041f)
+                            : __builtin_amdgcn_exp2f(accA[4 * g + j] * -2.885390082f);
+            if constexpr (DROP) {
+              const uint32_t idx = (uint32_t)row * 256u + (uint32_t)(dbA + 8 * g + 4 * hl + j);
+              kp[e] = keep((e & 1) ? key_b : key_a, idx, thr_a);
             }
-          }
+          };
+          auto stB = [&](int e) { te[e] = __builtin_amdgcn_rcpf(1.0f + te[e]); };
+          auto stC = [&](int e) {
+            if (!(e & 1)) te[e] = __builtin_fmaf(2.0f, te[e], -1.0f);              // tanh = 2 sigmoid(2 x) - 1
+            if ((e & 3) == 3) {                              // a pair of dims complete: a in te[e - 3], te[e - 1], b in te[e - 2], te[e]
+              const int g = e >> 3, j = (e >> 1) & 3;        // j odd
+              float a0 = te[e - 3], a1 = te[e - 1], b0 = te[e - 2], b1 = te[e];
+              pa[2 * g + (j >> 1)] = pack2(a0, a1);
+              pb[2 * g + (j >> 1)] = pack2(b0, b1);
+              // the scores use a, b AS SAVED (bf16): forward and backward see the same activations
+              unpack2(pa[2 * g + (j >> 1)], a0, a1);
+              unpack2(pb[2 * g + (j >> 1)], b0, b1);
+              if constexpr (DROP) {
+                a0 = kp[e - 3] ? a0 * dscale : 0.f; a1 = kp[e - 1] ? a1 * dscale : 0.f;
+                b0 = kp[e - 2] ? b0 * dscale : 0.f; b1 = kp[e] ? b1 * dscale : 0.f;
+              }
+              sc[ibA] = __builtin_fmaf(a0 * b0, wc[4 * g + j - 1], sc[ibA]);      // spelled out: the same two roundings for every block and lane
+              sc[ibA] = __builtin_fmaf(a1 * b1, wc[4 * g + j], sc[ibA]);
+            }
+          };
+          stA(s);
+          if (s >= 1) stB(s - 1);
+          if (s >= 2) stC(s - 2);
+          if (s == 15) { stB(15); stC(14); stC(15); }
           if (s == 15) {
             // lane (r, hh) holds dims {4 hh + j} (g = 0) and {8 + 4 hh + j} (g = 1); after the swap lanes hh = 0 hold dims 0-7,
             // lanes hh = 1 dims 8-15 of instance r: one 16-byte store each
@@ -404,11 +426,17 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
               ob[q] = sb[0]; ob[2 + q] = sb[1];
             }
             const unsigned o = (unsigned)row * 512u + (unsigned)(dbA + 8 * hl) * 2u;
+#ifndef MMF_F2_NOSTORE
             bst4(rsa, o, make_float4(__uint_as_float(oa[0]), __uint_as_float(oa[1]), __uint_as_float(oa[2]), __uint_as_float(oa[3])));
             bst4(rsb, o, make_float4(__uint_as_float(ob[0]), __uint_as_float(ob[1]), __uint_as_float(ob[2]), __uint_as_float(ob[3])));
+#else
+            asm volatile("" :: "v"(oa[0]), "v"(oa[1]), "v"(oa[2]), "v"(oa[3]), "v"(ob[0]), "v"(ob[1]), "v"(ob[2]), "v"(ob[3]), "v"(o));
+#endif
           }
         }
+#ifndef MMF_F2_GATE_NOWN
         if (s >= 8 && s < 12) wn[4 * slot + s - 8] = bld4(rg, vg, nw + (unsigned)((4 * slot + s - 8) * 1024));
+#endif
         if (s == 15) bias_init(accA, gp + dbN);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
       const int R = 16 * ig + i;
-      const float4 raw = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * 512 + 16 * (fg ^ (R & 15)));
+      const float4 raw = *reinterpret_cast<const float4*>(lds + F2_HIMG + R * F2_HROW + 16 * fg);
       float hv[8];
       unpack8(raw, hv);
       const float e = e_l[R];

@@ -25,9 +25,11 @@ from multimodalfusion_amd import build as B   # noqa: E402
 
 VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
+            "f2noact": ["-DMMF_F2_GATE_NOACT"], "f2nown": ["-DMMF_F2_GATE_NOWN"], "f2nomm": ["-DMMF_F2_GATE_NOMM"],
+            "f2nogate": ["-DMMF_F2_GATE_NOACT", "-DMMF_F2_GATE_NOWN", "-DMMF_F2_GATE_NOMM"],
             "f2base": ["-DMMF_F2_STAGE_BASE=16384"], "f2nop": ["-DMMF_DMA_M0NOP"],
             "f2noslp": ["-fno-slp-vectorize"],
-            "f2noswap": ["-DMMF_F2_NOSWAP"], "f2nostore": ["-DMMF_F2_NOSTORE"],
+            "f2nostore": ["-DMMF_F2_NOSTORE"], "f2nohstore": ["-DMMF_F2_NOHSTORE"], "f2nostores": ["-DMMF_F2_NOSTORE", "-DMMF_F2_NOHSTORE"],
             "f2r1": ["-DMMF_F2_REV_STORE_BRANCH"], "f2r2": ["-DMMF_F2_REV_GPAR"], "f2r3": ["-DMMF_F2_REV_SCHED"],
             "f2dbg": ["-DMMF_F2_DEBUG"],     # MMF_F2_DEBUG_MASK leaves phases of the bf16 fused forward out (mmf_amil_bf16_fwd2.hip)
             "nostore": ["-DMMF_DIAG_NOSTORE"], "noepi": ["-DMMF_DIAG_NOEPI"],
