@@ -10,7 +10,7 @@ for d in sys.argv[4:]:
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"instances": N, "dtype": dtype, "source": source, "kernels": {}}
 for name, cs in sorted(agg.items()):
-    if "kernel" not in name:
+    if "kernel" not in name or "at::" in name:
         continue
     m = {k: sum(v) / len(v) for k, v in cs.items()}
     e = {}
@@ -20,6 +20,7 @@ for name, cs in sorted(agg.items()):
     for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
         if k in m:
             e[k] = round(m[k], 1)
-    # the bench's kernel trace names the bf16 fused forward (both forms) amil_fwd_fused_bf16_kernel
-    out["kernels"]["amil_fwd_fused_bf16_kernel" if name == "amil_fwd_fused2_bf16_kernel" else name] = e
+    # the bench's kernel trace names both forms of the bf16 fused forward amil_fwd_fused_bf16_kernel and of K-dh dh_bf16_kernel
+    alias = {"amil_fwd_fused2_bf16_kernel": "amil_fwd_fused_bf16_kernel", "dh2_bf16_kernel": "dh_bf16_kernel"}
+    out["kernels"][alias.get(name, name)] = e
 print(json.dumps(out, indent=1))
