@@ -291,7 +291,7 @@ def roofline_of(prof, N, bf16):
         peak = BF16_MFMA_PEAK_TFLOPS / 6
         return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "peak_note": "dense bf16 MFMA peak / 6 products per fp32 product (bf16x3 split operands)",
-                "x_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
+                "x_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
                 "avg_launch_us": t_us, "flops_per_launch": kflops[dom]}
     if dom in kflops:
         ach = kflops[dom] / (t_us * 1e-6) / 1e12
