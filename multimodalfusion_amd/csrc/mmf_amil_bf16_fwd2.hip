@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     // (vmcnt(4)), x(kt+2) may still be in flight.  The loop body is BRANCH-FREE on purpose: the weight fragments are outputs
     // of asm statements whose data arrives later, and a conditional definition would let the compiler merge old and new
     // values with register copies placed right behind the (still unanswered) load.  The requests past the last chunk read
-    // beyond num_records (weights: zeros, no traffic) or refill a stage nobody reads any more; all are drained behind the loop.
+    // beyond num_records (weights: zeros, no traffic) or are turned into out-of-range requests (x: `kill`, or they would fetch
+    // the first bytes of the next rows, 12 % more x traffic); all are drained behind the loop.
     // The streaming phase outranks the partner workgroup's vector-bound phases on the SIMD (issue is arbitrated by priority,
     // then age): its loads and MFMAs are what the memory pipe waits for.  Measured -4 us of 121; raising the vector-bound
     // phases instead changes nothing.
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     {
       auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
         if (!(dbg & 2)) load_w(kt + 1, wnext);
-        if (!(dbg & 1)) lx.issue(kt + 2, stage(kt + 2));
+        if (!(dbg & 1)) lx.issue(kt + 2, stage(kt + 2), kt + 2 < nk ? 0u : 0x80000000u);
         uint32_t bits = 0;
         const uint32_t sC = __builtin_amdgcn_readfirstlane((uint32_t)(((kt >> 1) & 3) * 8192 + (kt >> 3) * 32 + (kt & 1) * 16) * 0x9E3779B1u);
         __builtin_amdgcn_sched_barrier(0);

@@ -90,11 +90,13 @@ struct DmaK {
       voff[i] = rr < nrows ? (unsigned)rr * (unsigned)ld * 2u + 16u * (unsigned)swz_slot(rl, lane & 7) : OOB;
     }
   }
-  __device__ inline void issue(int kt, char* stage) const {
+  // kill = 0x80000000 turns the request into an out-of-range one (zeros, no memory traffic): a branch-free loop's requests past
+  // the last chunk would otherwise read the first bytes of the NEXT row (k offset 2 L lands there), i.e. real traffic
+  __device__ inline void issue(int kt, char* stage, unsigned kill = 0u) const {
     const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(stage)) + (unsigned)wave * 1024u;
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)kt * 128u);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) dma16(rs, base + (unsigned)(i * NW) * 1024u, voff[i], soff);
+    for (int i = 0; i < NI; ++i) dma16(rs, base + (unsigned)(i * NW) * 1024u, voff[i] | kill, soff);
   }
 };
 
