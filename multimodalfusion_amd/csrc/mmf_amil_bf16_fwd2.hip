@@ -16,10 +16,10 @@
 //     (cvt_bf16_kernel, CvtSeg::transpose 3 / 4): one buffer_load_dwordx4 per lane IS an A fragment, a wave
 //     instruction reads 1 KB of contiguous memory, and each of the 4 waves loads only the rows it multiplies
 //     (wave w owns hidden features 64 w .. 64 w + 63; in the gate phase attention dims 64 p + 16 w .. + 15 of pass
-//     p = 0..3).  LDS holds only the x chunks (three 16 KB stages, LDS-DMA) and then the tile's h image (64 KB,
+//     p = 0..3).  LDS holds only the x chunks (three 16 KB stages, LDS-DMA) and then the tile's h image (66 KB,
 //     aliasing the stages).
-//   * the gate weights of a pass (32 rows = 16 tanh + 16 sigmoid rows of the same dims, K = 256: 64 VGPRs) are
-//     refilled k-step by k-step for the next pass right behind the MFMA that used them.
+//   * the gate weights of a pass (32 rows = 16 tanh + 16 sigmoid rows of the same dims, K = 256: 64 VGPRs) sit in one of
+//     two register sets; the other set is filled for the next pass, four k-steps per block.
 //
 // LDS map (bytes): [0, 49152) three x stages of [128 rows][128 B] (XOR-swizzled as mmf_gemm_dma.h), later
 //                  [0, 67584) h image [128 rows][528 B] (512 B of features + 16 B of padding);
