@@ -454,14 +454,14 @@ def other_configs_leg(dev, steps, warmup, gen):
             loss_of(model(**kw)).backward()
         return fn
 
-    def both(model, kw, loss_of):
+    def both(model, kw, loss_of, loss_of_graph=None):
         """Eager (Python + autograd + ~40-60 launches issued from the host per step: these steps are HOST-bound) and the same
         step captured into one hipGraph (graph.GraphedStep: device-resident dropout seed, fresh masks per replay), which
         takes the host off the critical path -- the figure that says what the kernels themselves cost."""
         from multimodalfusion_amd.graph import GraphedStep
         res = timeit(stepper(model, kw, loss_of))
         try:
-            gs = GraphedStep(stepper(model, kw, loss_of, static_grads=True))
+            gs = GraphedStep(stepper(model, kw, loss_of_graph or loss_of, static_grads=True))
             g = timeit(gs)
             res["graphed_ms_per_step"] = g["ms_per_step"]
             res["graphed_bags_per_s"] = g["bags_per_s"]
@@ -481,7 +481,11 @@ def other_configs_leg(dev, steps, warmup, gen):
     omic = MaxNet(input_dim=36, bag_loss="cox_surv").to(dev).train()
     ot = torch.rand(128, dtype=torch.float64) * 100
     oc = (torch.rand(128, device=dev, generator=gen) < 0.5).float()
-    out["config3_omic_maxnet_B128_cox"] = both(omic, {"genomic_features": rn(128, 36)}, lambda r: cox(risks=r[0], times=ot, c=oc))
+    # eager: event times arrive from the host every step (float64, pageable), as in the reference's loop; the captured step
+    # reads them from a device-resident buffer (a copy from pageable memory cannot be captured)
+    ot_dev = ot.to(dev)
+    out["config3_omic_maxnet_B128_cox"] = both(omic, {"genomic_features": rn(128, 36)}, lambda r: cox(risks=r[0], times=ot, c=oc),
+                                               lambda r: cox(risks=r[0], times=ot_dev, c=oc))
     del radio, omic
     for tag, n, dt in (("config4_mm_50k_f32", 50_000, torch.float32), ("config5_mm_100k_bf16", 100_000, torch.bfloat16)):
         xp = rn(n, 1024).to(dt)
