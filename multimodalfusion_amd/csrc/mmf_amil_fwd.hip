@@ -690,6 +690,7 @@ static inline bool short_grid(int64_t workgroups) {
 
 using TileNT128 = Tile<128, 128, 2, 2, true, true>;
 using TileNT64 = Tile<64, 64, 2, 2, true, true>;
+using TileNT32 = Tile<32, 64, 1, 2, true, true>;     // two waves: fills the chip where 64 x 64 tiles make <= 128 workgroups
 
 // rows-per-tile choice: big tiles once there is enough work to fill 256 CUs twice over
 static inline bool use_big_tiles(int64_t M, int N) { return (M / 128) * ((N + 127) / 128) >= 256; }
@@ -782,7 +783,14 @@ int launch_linear(LinearParams p, hipStream_t st) {
     using T = TileSp<64, 64, 2, 2>;
     return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
+  // a segmented (radio: M = 512, K = 4 x 1024) or otherwise long-K projection on <= 128 workgroups leaves half the CUs
+  // idle for the whole K loop: half-height tiles (two waves) put it on twice as many
+  static const int half_tiles = getenv("MMF_LINEAR_HALF_TILES") ? atoi(getenv("MMF_LINEAR_HALF_TILES")) : 1;   // A/B switch
   p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && p.nseg == 1 ? 1 : 0;
+  if (half_tiles && !p.deep && p.mt_count * p.nt_count <= 128 && p.M > 32 && p.K >= 1024) {   // (short plain grids: deep prefetch instead)
+    p.mt_count = (int)((p.M + 31) / 32);
+    return launch_tiled<TileNT32>("linear_nt_kernel", linear_nt_kernel<TileNT32>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  }
   return launch_tiled<TileNT64>("linear_nt_kernel", linear_nt_kernel<TileNT64>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
