@@ -786,7 +786,8 @@ int launch_linear(LinearParams p, hipStream_t st) {
   // a segmented (radio: M = 512, K = 4 x 1024) or otherwise long-K projection on <= 128 workgroups leaves half the CUs
   // idle for the whole K loop: half-height tiles (two waves) put it on twice as many
   static const int half_tiles = getenv("MMF_LINEAR_HALF_TILES") ? atoi(getenv("MMF_LINEAR_HALF_TILES")) : 1;   // A/B switch
-  p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && p.nseg == 1 ? 1 : 0;
+  static const int deep_seg = getenv("MMF_DEEP_SEG") ? atoi(getenv("MMF_DEEP_SEG")) : 1;      // A/B switch: deep prefetch for segmented inputs too
+  p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && (p.nseg == 1 || (deep_seg && p.kseg % (4 * KC) == 0)) ? 1 : 0;
   if (half_tiles && !p.deep && p.mt_count * p.nt_count <= 128 && p.M > 32 && p.K >= 1024) {   // (short plain grids: deep prefetch instead)
     p.mt_count = (int)((p.M + 31) / 32);
     return launch_tiled<TileNT32>("linear_nt_kernel", linear_nt_kernel<TileNT32>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
