@@ -480,6 +480,14 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
 #if defined(MMF_STAMPS) && defined(MMF_STAMP_FIRST_STAGE)   /* [2]: first stage (load + LDS write + barrier), [3]: count */
   if (lane == 0) { atomicAdd(&g_stamps[2], stamp_now() - t_enter); atomicAdd(&g_stamps[3], 1ull); }
 #endif
+  // Static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4):
+  // the younger wave of every SIMD loses each issue arbitration otherwise.  Measured on the 50k step, same box, two alternating
+  // pairs: K-dh -2.3 us, the projection -0.8, the gate -0.5; the TN tiles (m-contiguous operands) +1.0, so they keep priority 0.
+#ifndef MMF_GEMM_PRIO
+#define MMF_GEMM_PRIO 1
+#endif
+  constexpr bool half_prio = MMF_GEMM_PRIO && T::NT == 512 && T::A_KCONTIG;
+  if (half_prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int kt = 0; kt < nk; ++kt) {
     float* cur = lds + (kt & 1) * T::STAGE_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * T::STAGE_FLOATS;
@@ -543,6 +551,7 @@ __device__ inline void gemm_mainloop(LA& la, LB& lb, int nk, float* lds, f32x16 
     s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
 #endif
   }
+  if (half_prio) __builtin_amdgcn_s_setprio(0);
 #if defined(MMF_STAMPS) && !defined(MMF_STAMPS_LIGHT)
   if (lane == 0) {
     atomicAdd(&g_stamps[0], s_load); atomicAdd(&g_stamps[1], s_mfma);

@@ -27,6 +27,7 @@ VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
             "f2noact": ["-DMMF_F2_GATE_NOACT"], "f2nown": ["-DMMF_F2_GATE_NOWN"], "f2nomm": ["-DMMF_F2_GATE_NOMM"],
             "f2prio0": ["-DMMF_F2_PRIO=0"], "f2prio3": ["-DMMF_F2_PRIO=3"],
+            "gprio0": ["-DMMF_GEMM_PRIO=0"],
             "f2nogate": ["-DMMF_F2_GATE_NOACT", "-DMMF_F2_GATE_NOWN", "-DMMF_F2_GATE_NOMM"],
             "f2base": ["-DMMF_F2_STAGE_BASE=16384"], "f2nop": ["-DMMF_DMA_M0NOP"],
             "f2noslp": ["-fno-slp-vectorize"],
