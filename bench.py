@@ -15,7 +15,7 @@ RCCL all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == t
 Train mode as `model.train()` with --drop_out off (one Dropout(0.25) mask, the headline mode of
 BASELINE.md); rank 0 prints ONE JSON line.
 
-Steps are issued round-robin on `--inflight` HIP streams (default 3), each with its own flat gradient buffer
+Steps are issued round-robin on `--inflight` HIP streams (default 2), each with its own flat gradient buffer
 (multimodalfusion_amd/pipeline.py): bags are independent until the optimizer step (batch_size = 1 + gradient
 accumulation in the reference), and one bag's kernels leave CUs idle (224 of 256 in the row-parallel GEMMs, every
 kernel's tail, the latency-bound small kernels).  Every step is still one full forward + loss + backward of one bag
@@ -655,7 +655,7 @@ def main():
     bf16 = args.dtype == "bf16"
     if bf16:
         x = x.to(torch.bfloat16)
-    inflight = args.inflight if args.inflight > 0 else (2 if bf16 or args.gemm == "bf16x3" else 3)
+    inflight = args.inflight if args.inflight > 0 else 2      # 50k fp32, same box, alternating: 2 -> 1,372-1,379; 3 -> 1,351-1,357; 4 -> 1,315
     if args.gemm == "bf16x3" and not bf16:
         from multimodalfusion_amd import ops
         ops.set_gemm(1)

@@ -1,4 +1,4 @@
-"""GPU: bench.py's N > 1 path with bags in flight -- three HIP streams per rank, ONE all-reduce per bag issued on the bag's
+"""GPU: bench.py's N > 1 path with bags in flight -- two (the default) or three HIP streams per rank, ONE all-reduce per bag issued on the bag's
 stream (pipeline.BagsInFlight.all_reduce_slot) -- rehearsed with two ranks that share the box's one GPU (gloo instead of
 RCCL, which refuses two ranks on one device; MMF_BENCH_REHEARSAL=1).  Every rank must issue exactly the same number of
 collectives (a mismatch is a hang on RCCL) and the run must print one well-formed JSON line with n_gpus = 2."""
@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("inflight", [3, 1])
+@pytest.mark.parametrize("inflight", [3, 2, 1])
 def test_two_rank_rehearsal_counts_collectives(tmp_path, inflight):
     steps, warmup, blocks = 4, 2, 2
     tag = str(tmp_path / "collectives")
