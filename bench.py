@@ -394,7 +394,7 @@ def gemm_bf16x3_leg(model, x, dev, steps, warmup, inflight):
 
 def config5_leg(dev, steps, warmup, gen):
     """BASELINE config 5 on one GPU: bf16 storage, one 100,000 x 1024 bag, path head, train mode -- the HBM-roofline
-    run.  Strictly one bag at a time, plus the two-bags-in-flight rate; `roofline` is for its dominant kernel."""
+    run.  Strictly one bag at a time, plus the rates with two and three bags in flight; `roofline` is for its dominant kernel."""
     import torch
     N = 100_000
     model = build_model(dev, False)
@@ -406,8 +406,12 @@ def config5_leg(dev, steps, warmup, gen):
     for p in model.parameters():
         p.grad = None
     d2 = time_steps(make_step_inflight(model, x, dev, 1, 2), steps, warmup, 1)
+    for p in model.parameters():
+        p.grad = None
+    d3 = time_steps(make_step_inflight(model, x, dev, 1, 3), steps, warmup, 1)
     out = {"workload": "path_attention_mil small gated K=4, one 100000x1024 bf16 bag, train mode, fwd+nll_surv+bwd",
            "dtype": "bf16", "bags_per_s": steps / d1, "ms_per_step": ms, "two_bags_in_flight_bags_per_s": steps / d2,
+           "three_bags_in_flight_bags_per_s": steps / d3,
            "roofline": roofline_of(prof, N, True), "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(prof.items())},
            "whole_step": {"algorithmic_gbs": bytes_per_bag(N, True) / (ms * 1e-3) / 1e9,
                           "frac_hbm_peak": bytes_per_bag(N, True) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -655,7 +659,9 @@ def main():
     bf16 = args.dtype == "bf16"
     if bf16:
         x = x.to(torch.bfloat16)
-    inflight = args.inflight if args.inflight > 0 else 2      # 50k fp32, same box, alternating: 2 -> 1,372-1,379; 3 -> 1,351-1,357; 4 -> 1,315
+    # bags in flight by default -- 50k fp32, same box, alternating: 2 -> 1,372-1,379 bags/s; 3 -> 1,351-1,357; 4 -> 1,315 (one 8-wave
+    # workgroup per CU: only tails overlap); 100k bf16 (two 4-wave workgroups per CU): 2 -> 3,420-3,450; 3 -> 3,530-3,540
+    inflight = args.inflight if args.inflight > 0 else (3 if bf16 else 2)
     if args.gemm == "bf16x3" and not bf16:
         from multimodalfusion_amd import ops
         ops.set_gemm(1)
