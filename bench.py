@@ -15,7 +15,8 @@ RCCL all-reduce (SUM) of the flat gradient buffer per step (one bag per GPU == t
 Train mode as `model.train()` with --drop_out off (one Dropout(0.25) mask, the headline mode of
 BASELINE.md); rank 0 prints ONE JSON line.
 
-Steps are issued round-robin on `--inflight` HIP streams (default 2), each with its own flat gradient buffer
+Steps are issued round-robin on `--inflight` HIP streams (default 2 for fp32 bags, 3 for bf16 bags), each with its own
+resident bag and its own flat gradient buffer
 (multimodalfusion_amd/pipeline.py): bags are independent until the optimizer step (batch_size = 1 + gradient
 accumulation in the reference), and one bag's kernels leave CUs idle (224 of 256 in the row-parallel GEMMs, every
 kernel's tail, the latency-bound small kernels).  Every step is still one full forward + loss + backward of one bag
@@ -62,7 +63,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=0,
                     help="bags in flight per GPU: steps are issued round-robin on this many HIP streams, each with its "
                          "own gradient buffer (pipeline.BagsInFlight); 1 = strictly one bag at a time; "
-                         "0 = default: 3 (fp32), 2 (bf16: its 0.4 ms steps become host-bound beyond two; --gemm bf16x3: power-limited)")
+                         "0 = default: 2 (fp32: one 8-wave workgroup per CU, only kernel tails overlap; 1,372-1,379 bags/s with two, "
+                         "1,351-1,357 with three), 3 (bf16: two 4-wave workgroups per CU leave room for a third bag)")
     ap.add_argument("--autograd", action="store_true",
                     help="time the step through the autograd surface (model -> loss -> backward) instead of the one-call step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -150,8 +152,9 @@ def make_step(model, x, dev, flat=None, world=1, autograd=False):
 
 def make_step_inflight(model, x, dev, world, n_streams, autograd=False):
     """The same step (forward + nll_surv + backward, all parameter gradients materialised into a flat buffer, one
-    all-reduce per bag when world > 1) with `n_streams` bags in flight: step i runs on stream i % n_streams and owns
-    gradient slot i % n_streams."""
+    all-reduce per bag when world > 1) with `n_streams` bags in flight: step i runs on stream i % n_streams, owns
+    gradient slot i % n_streams and reads ITS OWN resident bag -- `x` is the first one, `distinct_bags` makes the others
+    (same shape, different values): concurrent bags must not share L2 / Infinity-Cache lines of one tensor."""
     import torch
     from multimodalfusion_amd.pipeline import BagsInFlight
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
@@ -160,22 +163,36 @@ def make_step_inflight(model, x, dev, world, n_streams, autograd=False):
     c = torch.tensor([0.0], device=dev)
     inv = 1.0 / world
     pipe = BagsInFlight(model, n_streams, dev)
-
-    def bag():
-        hazards, S, Y_hat, _ = model(path_features=x)
-        loss = loss_fn(hazards=hazards, S=S, Y=Y, c=c)
-        return loss * inv if world > 1 else loss
+    xs = distinct_bags(x, n_streams)
+    turn = [0]
 
     def step():
+        xi = xs[turn[0] % n_streams]
+        turn[0] += 1
         if autograd:
+            def bag():
+                hazards, S, Y_hat, _ = model(path_features=xi)
+                loss = loss_fn(hazards=hazards, S=S, Y=Y, c=c)
+                return loss * inv if world > 1 else loss
             loss = pipe.run(bag, accumulate=False)
         else:
-            loss = pipe.run_fused(model, x, Y, c, 0.0, loss_scale=inv, accumulate=False)[4]
+            loss = pipe.run_fused(model, xi, Y, c, 0.0, loss_scale=inv, accumulate=False)[4]
         if world > 1:
             pipe.all_reduce_slot()       # RCCL over xGMI: one collective per bag, on the bag's stream
         return loss
 
     return step
+
+
+def distinct_bags(x, n):
+    """`n` resident bags of x's shape and dtype: x itself and n - 1 more N(0,1) bags of other seeds (x is never copied)."""
+    import torch
+    out = [x]
+    for k in range(1, n):
+        g = torch.Generator(device=x.device)
+        g.manual_seed(977 + 31 * k)
+        out.append(torch.randn(x.shape, device=x.device, generator=g).to(x.dtype))
+    return out
 
 
 def time_blocks(step, steps, warmup, world, blocks):
@@ -603,12 +620,48 @@ def cpu_baseline(N, n_bags, threads=None):
                        f"value_1_thread: one bag on one thread")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves,
+    as children (`python -m torch.distributed.run ... bench.py <same arguments>`), before this process has made any GPU
+    call; relay rank 0's JSON line; a failed child is a non-zero exit.  Never exec: a parent that has touched the GPU must
+    not be replaced (and this one has not touched it anyway)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {args.gpus}-rank child run failed (exit {r.returncode}, {len(lines)} JSON lines)", file=sys.stderr)
+        sys.exit(r.returncode or 1)
+    if json.loads(lines[0]).get("n_gpus") != args.gpus:
+        print(f"bench.py: child run reported n_gpus != {args.gpus}", file=sys.stderr)
+        sys.exit(1)
+    print(lines[0], flush=True)
+    sys.exit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)            # does not return
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # the line's n_gpus is the number of ranks that ran: it must be what --gpus asked for
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         # RCCL exchanges buffers between the ranks' processes through IPC handles; this pool's host driver supports the
@@ -640,8 +693,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cuda", local)
     N = args.bag
 
@@ -733,9 +784,21 @@ def main():
                 d3 = time_steps(make_step(model, x2, dev, None, 1, True), args.steps, args.warmup, 1)
                 for p in model.parameters():
                     p.grad = None
+                prof2 = kernel_profile(make_step(model, x2, dev, None, 1), 10)
+                rl2 = roofline_of(prof2, n2, False)
                 extra[str(n2)] = {"bags_per_s": k2 / d2, "ms_per_step": ms2, **size_fractions(n2, ms2),
-                                  "autograd_surface_ms_per_step": 1e3 * d3 / args.steps}
+                                  "autograd_surface_ms_per_step": 1e3 * d3 / args.steps, "roofline": rl2,
+                                  "kernels_us": {k: round(v["avg_us"], 2) for k, v in sorted(prof2.items())}}
             out["other_sizes"] = extra
+            # bag-size sweep, one bag per step: is there a cliff between the small-tile and the wide-tile plans?
+            sweep = {}
+            for n2 in (4000, 10000, 16000, 24000, 40000, 60000):
+                x2 = torch.randn(n2, 1024, device=dev, generator=g)
+                k3 = max(40, min(k2, int(k2 * 10000 / n2)))
+                d2 = time_steps(make_step(model, x2, dev, None, 1), k3, args.warmup, 1)
+                sweep[str(n2)] = {"ms_per_step": 1e3 * d2 / k3, "frac_fp32_mfma_peak": size_fractions(n2, 1e3 * d2 / k3)["frac_fp32_mfma_peak"]}
+                del x2
+            out["n_sweep"] = sweep
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)
             if not bf16 and args.gemm == "f32":
                 # two bags in flight: this mode keeps the package at its power limit by itself (1,907 bags/s with two,

@@ -79,10 +79,12 @@ typedef struct mmf_amil_desc {
                               *                       leading products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
                               *                       (csrc/mmf_gemm_split.h).  Same error against an fp64 product as
                               *                       mode 0 (tests/test_gpu_split.py), 2.67 x its instruction rate.
-                              *                       Every bag size, gated or not (wide tiles from 20,480 instances at H = 256 -- 80 rows per CU; a tuning detail of the launcher, not a contract
-                              *                       at H = 256, 64-row tiles below); the radio head's segmented
-                              *                       projection and the stand-alone scorer run mode 0.  Operands
-                              *                       within one bf16 ulp of FLT_MAX, or infinite, give NaN. */
+                              *                       Every bag size, gated or not (which tile a bag size takes is a
+                              *                       tuning detail of the launcher, not a contract); the radio head's
+                              *                       segmented projection and the stand-alone scorer run mode 0.
+                              *                       Finite operands stay finite (values beyond the largest bf16 are
+                              *                       split around a clamped first plane); infinite operands give NaN,
+                              *                       as in mode 0. */
 } mmf_amil_desc;
 #define MMF_GEMM_F32 0
 #define MMF_GEMM_BF16X3 1

@@ -64,8 +64,6 @@ static int launch_tiled_b(const char* name, void (*kern)(P), const P& p, int gri
 // =============================================================================================
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvtParams p) {
   const int b = blockIdx.x;
-  if (b == 0)
-    for (int i = threadIdx.x; i < p.nzero; i += 256) p.zero[i] = 0u;
   int si = 0;
   for (int i = 1; i < p.nseg; ++i)
     if (b >= p.seg[i].block_begin) si = i;
@@ -105,7 +103,7 @@ using TileB128 = Tile<128, 256, 2, 4, true, true, 4, true>;
 
 // 256-row tiles unless 128-row tiles fill the 256 CUs in fewer (half-length) rounds
 static inline int pick_bm(int64_t rows, int ntn) {
-  static const int env = getenv("MMF_BF16_BM") ? atoi(getenv("MMF_BF16_BM")) : 0;   // tuning override
+  static const int env = tune_int("MMF_BF16_BM", 0);   // tuning override
   if (env == 128 || env == 256) return env;
   const int64_t t256 = ((rows + 255) / 256) * ntn, t128 = ((rows + 127) / 128) * ntn;
   const double c256 = (double)((t256 + 255) / 256) * 2.15, c128 = (double)((t128 + 255) / 256) * 1.15;
@@ -659,7 +657,7 @@ __global__ __launch_bounds__(512) void amil_fwd_fused_bf16_kernel(FusedFwdParams
 
 int fused_fwd_tiles(int64_t N) { return (int)((N + 127) / 128); }
 bool fused_fwd_ok(int64_t N, int L, int H, int D) {     // callers also require gated && D == 256 (8 waves x 32 dims)
-  static const int env = getenv("MMF_BF16_FUSED") ? atoi(getenv("MMF_BF16_FUSED")) : 1;   // A/B switch
+  static const int env = tune_int("MMF_BF16_FUSED", 1);   // A/B switch
   (void)D;
   return env && H == 256 && L % 64 == 0 && fused_fwd_tiles(N) <= 4096;
 }
@@ -1190,7 +1188,7 @@ __global__ __launch_bounds__(T::NT) void tn_bf16_kernel(TnBfParams p) {
 }
 
 int tn_bf16_splits(int64_t K, int total_tiles) {
-  static const int env = getenv("MMF_BF16_TN_SPLITS") ? atoi(getenv("MMF_BF16_TN_SPLITS")) : 0;   // tuning override
+  static const int env = tune_int("MMF_BF16_TN_SPLITS", 0);   // tuning override
   int splits = 256 / (total_tiles > 0 ? total_tiles : 1);
   if (splits >= 8) splits &= ~7;           // whole splits per XCD (launch_tn_bf16's block map)
   if (env > 0) splits = env;
@@ -1213,7 +1211,7 @@ int launch_tn_bf16(TnBfParams p, hipStream_t st) {
   }
   if (blocks == 0) return MMF_OK;
   p.total_tiles = blocks;
-  static const int env_xcd = getenv("MMF_BF16_TN_XCD") ? atoi(getenv("MMF_BF16_TN_XCD")) : 1;   // tuning override
+  static const int env_xcd = tune_int("MMF_BF16_TN_XCD", 1);   // tuning override
   p.xcd_map = env_xcd && p.splits % 8 == 0;
   return launch_tiled_b<T>("tn_bf16_kernel", tn_bf16_kernel<T>, p, p.splits * blocks, T::LDS_BYTES, st);
 }

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void dh2_bf16_kernel(DhBfParams p) {
 }
 
 bool dh2_bf16_ok(int64_t N, int H, int D, int gated) {
-  static const int env = getenv("MMF_BF16_DH2") ? atoi(getenv("MMF_BF16_DH2")) : 1;   // A/B switch
+  static const int env = tune_int("MMF_BF16_DH2", 1);   // A/B switch
   return env && gated && H == 256 && D == 256 && N > 0;
 }
 

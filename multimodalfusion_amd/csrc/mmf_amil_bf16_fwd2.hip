@@ -530,20 +530,20 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
 }
 
 bool fused_fwd2_ok(int64_t N, int L, int H, int D) {
-  static const int env = getenv("MMF_BF16_FUSED") ? atoi(getenv("MMF_BF16_FUSED")) : 2;   // A/B switch: 1 = first form, 0 = unfused kernels
+  static const int env = tune_int("MMF_BF16_FUSED", 2);   // A/B switch: 1 = first form, 0 = unfused kernels
   return env == 2 && H == 256 && D == 256 && L % 128 == 0 && fused_fwd_tiles(N) <= 4096;
 }
 
 int launch_fused_fwd2_bf16(FusedFwdParams p, int gated, hipStream_t st) {
   if (!gated || p.D != 256 || p.L % 128 != 0 || !p.w1f || !p.wabf) return MMF_ERR_SHAPE;
   p.mt_count = fused_fwd_tiles(p.N);
-  static const int dbg = getenv("MMF_F2_DEBUG_MASK") ? atoi(getenv("MMF_F2_DEBUG_MASK")) : 0;
-  static const int hl = getenv("MMF_F2_HLOOP") ? atoi(getenv("MMF_F2_HLOOP")) : 1;       // A/B switch
+  static const int dbg = tune_int("MMF_F2_DEBUG_MASK", 0);
+  static const int hl = tune_int("MMF_F2_HLOOP", 1);       // A/B switch
   p.stagger = dbg;
   p.hash_in_loop = hl;
   const bool hloop = p.p_h > 0.f && p.L == 1024 && p.hash_in_loop;
   auto kern = hloop ? amil_fwd_fused2_bf16_kernel<true> : amil_fwd_fused2_bf16_kernel<false>;
-  static const int lds_env = getenv("MMF_F2_LDS") ? atoi(getenv("MMF_F2_LDS")) : 0;     // experiment: > 80 KB forces one workgroup per CU
+  static const int lds_env = tune_int("MMF_F2_LDS", 0);     // experiment: > 80 KB forces one workgroup per CU
 #ifdef MMF_F2_REV_GPAR
   const int lds_bytes = lds_env > 0 ? lds_env : F2_LDS_BYTES;       // experiment: any size (the gate parameters are not in LDS)
 #else

@@ -1313,7 +1313,7 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 
 // > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
 static inline bool dh_short_grid(int64_t N, int H, int split = 0) {       // the 64x64 tiles on a grid of at most 512 workgroups
-  static const int cap = getenv("MMF_DH_SHORT_MAX") ? atoi(getenv("MMF_DH_SHORT_MAX")) : 512;   // tuning override
+  static const int cap = tune_int("MMF_DH_SHORT_MAX", 512);   // tuning override
   return !use_wide_tiles(N, H, split) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= cap;
 }
 // the split-operand mode's 64 x 64 K-dh tiles: every bag below its wide tiles
@@ -1327,7 +1327,7 @@ bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {
 int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
 
 int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split) {
-  static const int env = getenv("MMF_FUSED_PREP") ? atoi(getenv("MMF_FUSED_PREP")) : 1;
+  static const int env = tune_int("MMF_FUSED_PREP", 1);
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
   const int sm = dh_split_small_ok(N, H, D, gated, split);
@@ -1401,8 +1401,8 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
   }
   using T = Tile<64, 64, 2, 2, true, false>;
   p.mt_count = (int)((p.N + 63) / 64); p.nt_count = (p.H + 63) / 64;
-  static const int env_deep = getenv("MMF_DEEP") ? atoi(getenv("MMF_DEEP")) : 1;     // A/B switch
-  static const int deep_cap = getenv("MMF_DEEP_MAX") ? atoi(getenv("MMF_DEEP_MAX")) : 1024;   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
+  static const int env_deep = tune_int("MMF_DEEP", 1);     // A/B switch
+  static const int deep_cap = tune_int("MMF_DEEP_MAX", 1024);   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
   p.deep = env_deep && (int64_t)p.mt_count * p.nt_count <= deep_cap && p.g.gated && (2 * p.g.D / KC) % 4 == 0 ? 1 : 0;
   if (p.fused_prep)
     return launch_tiled_extra<T>("bwd_dh_kernel", bwd_dh_kernel<T, true>, p, grid_for_tiles(p.mt_count, p.nt_count),
@@ -1428,14 +1428,14 @@ int launch_nn(NnParams p, hipStream_t st) {
 // instead of 32, which is what the per-CU load rate needs (profiles/r01/load_rate.txt); the price is twice the
 // splits (slab traffic) for the same number of workgroups, so it is used only for long K.
 int tn_tile_dim(int64_t K, int D_gate) {
-  static const int env = getenv("MMF_TN_WIDE") ? atoi(getenv("MMF_TN_WIDE")) : 1;
-  static const int kmin = getenv("MMF_TN_WIDE_MIN") ? atoi(getenv("MMF_TN_WIDE_MIN")) : 12288;   // tuning override
+  static const int env = tune_int("MMF_TN_WIDE", 1);
+  static const int kmin = tune_int("MMF_TN_WIDE_MIN", 12288);   // tuning override
   if (!env || K < kmin) return 128;       // measured crossover: 10k bags 236 vs 243 us per step, 14k 294 vs 289
   (void)D_gate;
   return 256;
 }
 int tn_splits(int64_t K, int total_tiles, int tile) {
-  static const int env_splits = getenv("MMF_TN_SPLITS") ? atoi(getenv("MMF_TN_SPLITS")) : 0;   // tuning override
+  static const int env_splits = tune_int("MMF_TN_SPLITS", 0);   // tuning override
   int splits = (tile == 256 ? 256 : 512) / (total_tiles > 0 ? total_tiles : 1);
   if (env_splits > 0) splits = env_splits;
   const int64_t max_splits = (K + 127) / 128;
@@ -1478,7 +1478,7 @@ static int launch_tn_t(TnParams p, hipStream_t st) {
   }
   if (blocks == 0) return MMF_OK;
   p.total_tiles = tiles;
-  static const int env_xcd = getenv("MMF_TN_XCD") ? atoi(getenv("MMF_TN_XCD")) : -1;
+  static const int env_xcd = tune_int("MMF_TN_XCD", -1);
   p.xcd_map = env_xcd == 0 ? 0 : 2;      // default: the table (same speed, a third less HBM traffic: PMC 682 -> 477 MB)
   if (p.xcd_map == 2) {
     // Pack groups (= the tiles of one problem in one split: they share the A or the B panel) into 8 bins, one per

@@ -683,8 +683,8 @@ static int launch_tiled(const char* name, void (*kern)(P), const P& p, int grid,
 
 // a grid this short leaves every workgroup alone on its CU: nothing hides a memory round trip but deeper prefetch
 static inline bool short_grid(int64_t workgroups) {
-  static const int env = getenv("MMF_DEEP") ? atoi(getenv("MMF_DEEP")) : 1;     // A/B switch
-  static const int cap = getenv("MMF_DEEP_MAX") ? atoi(getenv("MMF_DEEP_MAX")) : 1024;   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
+  static const int env = tune_int("MMF_DEEP", 1);     // A/B switch
+  static const int cap = tune_int("MMF_DEEP_MAX", 1024);   // tuning override (10k bag, 628 workgroups: 252 -> 242 us per step)
   return env && workgroups <= cap;
 }
 
@@ -705,7 +705,7 @@ using TileW = Tile<ROWS, 256, 1, 8, true, true>;
 // tile height that minimises rounds x blocks over the 256 CUs (0.35: per-tile prologue / epilogue, in 32-row blocks);
 // 208 = six blocks + a 16-row half block (Tile::HALF): a 50k bag becomes 241 tiles on 241 CUs instead of 224
 int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
-  static const int env = getenv("MMF_WIDE_ROWS") ? atoi(getenv("MMF_WIDE_ROWS")) : 0;   // tuning override
+  static const int env = tune_int("MMF_WIDE_ROWS", 0);   // tuning override
   if (env > 0 && ((env != 208 && env != 48) || allow_half)) return env;
   int best = 224;
   double bestc = 1e30;
@@ -720,8 +720,8 @@ int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
   return best;
 }
 bool use_wide_tiles(int64_t M, int N, int split) {
-  static const int env = getenv("MMF_WIDE") ? atoi(getenv("MMF_WIDE")) : 1;
-  static const int min_env = getenv("MMF_WIDE_MIN") ? atoi(getenv("MMF_WIDE_MIN")) : 0;   // tuning override
+  static const int env = tune_int("MMF_WIDE", 1);
+  static const int min_env = tune_int("MMF_WIDE_MIN", 0);   // tuning override
   // crossover against the 64-row tiles, one bag per step: exact fp32 16,384 rows (0.300 vs 0.329 ms there); the
   // split-operand tiles cross later -- 16,384: 0.307 wide vs 0.284 small, 24,000: 0.355 vs 0.412
   const int min_rows = min_env > 0 ? min_env : (split ? 80 * 256 : 64 * 256);
@@ -741,7 +741,7 @@ int split_min_rows() {
   // every bag takes the split tiles, so that an instance's score does not depend on the size of the bag it is scored
   // in, bit for bit (heat-map batches of 512 patches vs the whole slide: tests/test_gpu_infer.py) -- the accumulation
   // order is the same on every split tile shape, but not between a split tile and an exact-fp32 one
-  static const int env = getenv("MMF_SPLIT_MIN") ? atoi(getenv("MMF_SPLIT_MIN")) : 1;   // tuning override
+  static const int env = tune_int("MMF_SPLIT_MIN", 1);   // tuning override
   return env;
 }
 template <int ROWS, int WM, int WN, int GM = 1>
@@ -757,8 +757,8 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (p.M <= 0) return MMF_OK;
   const bool can_split = p.split && p.K % (4 * SKC) == 0 && p.nseg == 1;
   if (can_split && use_wide_tiles(p.M, p.N, 1)) {
-    static const int rows = getenv("MMF_SPLIT_ROWS") ? atoi(getenv("MMF_SPLIT_ROWS")) : 224;
-    static const int gm = getenv("MMF_SPLIT_GM") ? atoi(getenv("MMF_SPLIT_GM")) : 1;      // A/B switch
+    static const int rows = tune_int("MMF_SPLIT_ROWS", 224);
+    static const int gm = tune_int("MMF_SPLIT_GM", 1);      // A/B switch
     if (gm == 2 && rows == 224) return launch_linear_split<224, 1, 8, 2>(p, st);
     if (rows == 256) return launch_linear_split<256, 2, 4>(p, st);
     if (rows == 192) return launch_linear_split<192, 1, 8>(p, st);
@@ -785,8 +785,8 @@ int launch_linear(LinearParams p, hipStream_t st) {
   }
   // a segmented (radio: M = 512, K = 4 x 1024) or otherwise long-K projection on <= 128 workgroups leaves half the CUs
   // idle for the whole K loop: half-height tiles (two waves) put it on twice as many
-  static const int half_tiles = getenv("MMF_LINEAR_HALF_TILES") ? atoi(getenv("MMF_LINEAR_HALF_TILES")) : 1;   // A/B switch
-  static const int deep_seg = getenv("MMF_DEEP_SEG") ? atoi(getenv("MMF_DEEP_SEG")) : 1;      // A/B switch: deep prefetch for segmented inputs too
+  static const int half_tiles = tune_int("MMF_LINEAR_HALF_TILES", 0);   // A/B switch (off: measured slower or equal)
+  static const int deep_seg = tune_int("MMF_DEEP_SEG", 1);      // A/B switch: deep prefetch for segmented inputs too
   p.deep = short_grid(p.mt_count * p.nt_count) && (p.K / KC) % 4 == 0 && (p.nseg == 1 || (deep_seg && p.kseg % (4 * KC) == 0)) ? 1 : 0;
   if (half_tiles && !p.deep && p.mt_count * p.nt_count <= 128 && p.M > 32 && p.K >= 1024) {   // (short plain grids: deep prefetch instead)
     p.mt_count = (int)((p.M + 31) / 32);
@@ -839,7 +839,7 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
   // R = whole rounds of 512 tall tiles in the bag.  MMF_GATE_MIXED=2: A + E only (the first version of this: 133 -> 128 us).
   // split-operand tiles: their main loop is short against their epilogue, and the out-of-phase plan's extra short tiles
   // cost more than the phase offset wins (A + E only: 91.2 us; dephased: 96.4; uniform tiles: 94.5)
-  static const int env_gate = getenv("MMF_GATE_MIXED") ? atoi(getenv("MMF_GATE_MIXED")) : -1;   // A/B switch
+  static const int env_gate = tune_int("MMF_GATE_MIXED", -1);   // A/B switch
   const int env_mixed = env_gate >= 0 ? env_gate : (split ? 2 : 1);
   int64_t mt = (p.N + 127) / 128;
   const int64_t slots = 512, total = mt * p.nt_count;
@@ -884,7 +884,7 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
 int pool_groups(int64_t N) {
   // one 4-wave workgroup per CU: the partial kernel streams h at ~5 TB/s with 256, 512 or 1024 groups alike
   // (measured), and the merge reads one partial per group
-  static const int cap = getenv("MMF_POOL_GROUPS") ? atoi(getenv("MMF_POOL_GROUPS")) : 256;   // tuning override
+  static const int cap = tune_int("MMF_POOL_GROUPS", 256);   // tuning override
   int64_t g = (N + 63) / 64;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
@@ -907,7 +907,7 @@ int launch_pool_merge(PoolParams p, hipStream_t st) {
   // Merging inside the single-workgroup tail kernel saves a launch and loses more than that: measured, one bag per
   // step, separate merge vs merge in the tail: 1k 0.0995 vs 0.1016 ms, 2k 0.1085 vs 0.1146, 4,096 (64 groups) 0.1236 vs
   // 0.1370.  Off by default; MMF_TAIL_MERGE=<max groups, <= 64> turns it back on.
-  static const int tail_merge = getenv("MMF_TAIL_MERGE") ? atoi(getenv("MMF_TAIL_MERGE")) : 0;
+  static const int tail_merge = tune_int("MMF_TAIL_MERGE", 0);
   p.merge_in_tail = p.tail.Wk && p.n_groups <= (tail_merge < TAIL_MERGE_MAX ? tail_merge : TAIL_MERGE_MAX) ? 1 : 0;
   if (!p.merge_in_tail) {
     ProfScope ps("pool_merge_kernel", st);

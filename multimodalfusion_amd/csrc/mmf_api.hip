@@ -119,7 +119,7 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   // 42 of 38 at N = 50k.  Large-bag tile only, at most 12 % more splits.
   w.splits_g = splits; w.k_per_split_g = w.k_per_split;
   {
-    static const int env = getenv("MMF_TN_GATE_SPLITS") ? atoi(getenv("MMF_TN_GATE_SPLITS")) : -1;   // tuning override
+    static const int env = mmf::tune_int("MMF_TN_GATE_SPLITS", -1);   // tuning override
     const int t1 = ((H + td - 1) / td) * ((L + td - 1) / td), t2 = tiles - t1;
     int sg = splits;
     if (td == 256 && t2 > 0 && splits >= 8) {
@@ -181,7 +181,6 @@ struct AmilWsBf {
   float *M_step, *dM_step;
   bf16_t *w1, *wab, *wabT, *h, *a, *b, *du, *dP;
   float *s_part, *partials, *stats, *p, *ds, *dbc_part, *dwc_part;
-  unsigned* sched;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab;
   int parts, groups, splits, k_per_split, mstk, dbc_cap;
   size_t bytes;
@@ -219,7 +218,6 @@ static AmilWsBf carve_bf16(void* base, int64_t N, int L, int H, int D, int gated
     w.partials = take32((size_t)(w.groups > tiles ? w.groups : tiles) * (2 + H));
   }
   w.stats = take32(4);
-  w.sched = reinterpret_cast<unsigned*>(take32(F2_SCHED_WORDS));
   if (infer) {
     w.bytes = off;
     return w;
@@ -451,14 +449,13 @@ static int amil_bf16_forward_impl(const mmf_amil_desc* d, const uint16_t* x, voi
     else cvt(d->Wb, w.wab + (size_t)d->D * d->H, d->D, d->H, d->H, 0, 0);
     if (!infer) cvt(d->Wb, w.wabT, d->D, d->H, w.mstk, 32, dh2 ? 5 : 2);
   }
-  if (fused2) { cp.zero = w.sched; cp.nzero = F2_SCHED_WORDS; }
   if (int e = launch_cvt_bf16(cp, st)) return e;
 
   if (fused2 || (d->gated && d->D == 256 && fused_fwd_ok(d->N, d->L, d->H, d->D))) {   // `small` gated stack: one kernel for projection + scoring + pooling partials
     FusedFwdParams fp{};
     fp.x = x; fp.w1 = w.w1; fp.b1 = d->b1;
     fp.Wa = w.wab; fp.Wb = d->gated ? w.wab + (size_t)d->D * d->H : nullptr;
-    fp.w1f = w.w1; fp.wabf = w.wab; fp.sched = w.sched;
+    fp.w1f = w.w1; fp.wabf = w.wab;
     fp.ba = d->ba; fp.bb = d->bb; fp.Wc = d->Wc; fp.bc = d->bc;
     fp.h = infer ? nullptr : w.h; fp.a = w.a; fp.b = w.b;       // a / b are null when carved for inference
     fp.A_raw = A_raw; fp.partials = w.partials;

@@ -52,7 +52,7 @@ struct CvtSeg {            // dst[r][c0 + c] (ld = dst_ld) = bf16(src[r][c]);  t
   const float* src; bf16_t* dst;
   int rows, cols, dst_ld, c0, transpose, block_begin;
 };
-struct CvtParams { CvtSeg seg[6]; int nseg; unsigned* zero; int nzero; };   // zero[0 .. nzero): scheduler words cleared by block 0 (fused forward, second form)
+struct CvtParams { CvtSeg seg[6]; int nseg; };
 
 struct LinearBfParams {    // y[M x N] = bf16(drop(relu(x[M x K] . W[N x K]^T + bias)))
   const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
@@ -122,9 +122,7 @@ struct FusedFwdParams {     // fused forward (H = 256): instance projection + ga
   int mt_count;
   int hash_in_loop;             // second form: projection dropout bits hashed inside the main loop (L == 1024)
   int stagger;                  // diagnostic builds only (-DMMF_F2_DEBUG): mask of phases to leave out
-  unsigned* sched;              // second form: [0] next work item, [8 + 256 xcc + cu] workgroups arrived on that CU; zeroed by cvt_bf16_kernel
 };
-constexpr int F2_SCHED_WORDS = 8 + 8 * 256;
 int fused_fwd_tiles(int64_t N);
 bool fused_fwd_ok(int64_t N, int L, int H, int D);
 int launch_fused_fwd_bf16(FusedFwdParams p, int gated, hipStream_t st);

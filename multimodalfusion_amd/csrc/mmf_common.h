@@ -2,8 +2,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef MMF_TUNE
+#include <cstdlib>
+#endif
 
 namespace mmf {
+
+// ---- launch-plan tuning knobs ------------------------------------------------------------
+// The shipped library takes its launch plan from the call's arguments alone: tune_int() is the constant default.
+// Only a tuning build (-DMMF_TUNE: tools/diag_build.py tune -> _diag/libmmf_tune.so, loaded through MMF_LIB_PATH by
+// the sweep scripts under tools/) reads the environment, once per process and knob.
+#ifdef MMF_TUNE
+inline int tune_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+constexpr int tune_int(const char*, int dflt) { return dflt; }
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

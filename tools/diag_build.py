@@ -4,6 +4,8 @@
     python tools/diag_build.py            # -> multimodalfusion_amd/_diag/libmmf_{noload,nomfma}.so
     MMF_LIB_PATH=multimodalfusion_amd/_diag/libmmf_noload.so python bench.py --no-cpu-baseline ...
 
+tune:   the product library with the launchers' MMF_* environment overrides compiled in (csrc/mmf_common.h: tune_int);
+        the shipped library reads no environment variable -- every sweep script under tools/ loads this one
 noload: the main loops stage nothing after the first chunk (MFMA + LDS reads + epilogue only)
 nomfma: the main loops issue no MFMA (global loads + LDS writes + barriers + epilogue only)
 nofrag: noload + the fp32 core reads its LDS fragments once per chunk only (MFMA + barriers + epilogue)
@@ -23,7 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from multimodalfusion_amd import build as B   # noqa: E402
 
-VARIANTS = {"noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
+VARIANTS = {"tune": ["-DMMF_TUNE"],      # the product kernels + the MMF_* environment overrides of the launch plans (tools/README.md)
+            "noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
             "f2noact": ["-DMMF_F2_GATE_NOACT"], "f2nown": ["-DMMF_F2_GATE_NOWN"], "f2nomm": ["-DMMF_F2_GATE_NOMM"],
             "f2prio0": ["-DMMF_F2_PRIO=0"], "f2prio3": ["-DMMF_F2_PRIO=3"],
@@ -54,6 +57,8 @@ def main():
         os.makedirs(objdir, exist_ok=True)
         jobs = []
         objs = []
+        if name != "tune" and "-DMMF_TUNE" not in flags:
+            flags = flags + ["-DMMF_TUNE"]        # every diagnostic library honours the overrides too
         for s in B.SOURCES:
             obj = os.path.join(objdir, s.replace(".hip", ".o"))
             objs.append(obj)

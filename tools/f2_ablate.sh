@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # kernel time of the bf16 fused forward with phases left out (diagnostic build f2dbg), two and one workgroup per CU
 R=$GRAFT_REPO_ROOT
 for l in 0 100000; do for m in "$@"; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # gate_fwd tile plan (MMF_GATE_MIXED 0 / 1 / 2) under both gemm modes, one 50k bag per step
 for g in bf16x3 f32; do
   for m in 1 2 0; do

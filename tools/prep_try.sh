@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # K-prep fused into the 64-row K-dh tiles up to which grid size?  (one bag per step, both gemm modes)
 for n in 10000 14000; do
   for cap in 512 1024; do

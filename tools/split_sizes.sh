@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # one-bag step time by bag size, exact fp32 vs bf16x3 with the small split tiles forced (MMF_SPLIT_MIN=1)
 for n in ${SIZES:-1000 2000 4096 6000 10000 14000}; do
   for g in f32 bf16x3; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # K-split balance of the split-operand TN kernel: plain (dW1) splits x gate (d[Wa;Wb]) splits, 4 s1 + 2 sg <= 256
 for pair in "42 44" "40 48" "38 52" "36 56" "34 60"; do
   set -- $pair

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # A/B of the split-operand (bf16x3) GEMM path: parity tests with MMF_GEMM=1, then kernel stats of the 50k step.
 R=$GRAFT_REPO_ROOT
 export MMF_GEMM=1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # usage: tools/sweep.sh "<ENV1=a ENV2=b>" "<...>" ...   -> one bench line (kernel us) per env combo
 for combo in "$@"; do
   echo "== $combo"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # usage: tools/sweep_n.sh N "<ENV...>" ...  -> kernel us per env combo at bag size N (eval of tile heuristics)
 N=$1; shift
 for combo in "$@"; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # fp32 headline with TN split / XCD-map overrides
 for cfg in "0 0" "40 0" "40 1" "32 1" "48 1"; do
   set -- $cfg

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # from which bag size do the wide (224 x 256, one workgroup per CU) tiles beat the 64-row tiles?  both gemm modes
 for n in 16384 24000 32768 40000; do
   for wm in 16384 65536; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# environment overrides exist in the tuning build only (python tools/diag_build.py tune)
+export MMF_LIB_PATH=${MMF_LIB_PATH:-multimodalfusion_amd/_diag/libmmf_tune.so}
 # 48- / 64-row wide tiles on bags below the usual wide-tile crossover: step time and parity
 R=$GRAFT_REPO_ROOT
 for n in 6000 10000 14000; do
