@@ -85,6 +85,14 @@ typedef struct mmf_amil_desc {
                               *                       Finite operands stay finite (values beyond the largest bf16 are
                               *                       split around a clamped first plane); infinite operands give NaN,
                               *                       as in mode 0. */
+  uint32_t* sync;            /* optional DEVICE array of `sync_words` 32-bit words, or NULL.  Tick words of the launches in
+                              * which several workgroups share an output tile (K-split projections of short grids: each
+                              * writes a partial tile, the last to arrive -- found through one of these words -- sums them
+                              * in a fixed order and finishes the tile; no workgroup waits for another).  Contract: zero
+                              * before the first call that sees it; every call leaves it zero; calls that may run at the
+                              * same time (different streams) need different arrays.  NULL / too few words: such launches
+                              * fall back to one workgroup per tile (same results to fp32 rounding, slower small bags). */
+  int32_t sync_words;        /* 1024 covers every shape */
 } mmf_amil_desc;
 #define MMF_GEMM_F32 0
 #define MMF_GEMM_BF16X3 1
@@ -200,11 +208,15 @@ int mmf_attn_net_backward(const mmf_amil_desc* desc, const float* x, void* works
  *   replaces torch.cat + nn.Linear of model_attention_mil_radio.py:80-82 (reduce_dim; the modality
  *   bags are never concatenated in memory) and the instance projections generally.
  *   x_segs: HOST array of nseg (<= 4) device pointers, each [M x kseg]; K = nseg*kseg; K % 32 == 0.
+ *   workspace / sync (both optional, may be NULL): scratch for the K-split plan of short grids (a 512-row radiology bag
+ *   against the 4096-wide reduce_dim is 128 output tiles with a 128-chunk K loop each: split four ways -- one modality
+ *   segment per workgroup -- it fills the chip) and the tick words it needs, under mmf_amil_desc::sync's contract.
  * ------------------------------------------------------------------------------------------- */
+size_t mmf_linear_forward_workspace_bytes(int64_t M, int32_t N, int32_t nseg, int32_t kseg);   /* 0: the shape is not split */
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
                        const float* W, const float* bias, int32_t N, int32_t act,
                        float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* seed_dev,
-                       float* y, void* stream);
+                       float* y, void* workspace, size_t workspace_bytes, uint32_t* sync, int32_t sync_words, void* stream);
 
 size_t mmf_linear_backward_workspace_bytes(int64_t M, int32_t N, int32_t K);
 /* dy [M x N] (gradient w.r.t. the pre-activation output) -> dW [N x K], db [N] (may be NULL),

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -25,6 +25,7 @@ class AmilDesc(C.Structure):
         ("Wb", C.c_void_p), ("bb", C.c_void_p), ("Wc", C.c_void_p), ("bc", C.c_void_p),
         ("p_h", C.c_float), ("p_att", C.c_float), ("seed", C.c_uint32),
         ("seed_dev", C.c_void_p), ("trace", C.c_void_p), ("concurrent", C.c_int32), ("gemm", C.c_int32),
+        ("sync", C.c_void_p), ("sync_words", C.c_int32),
     ]
 
 
@@ -88,9 +89,11 @@ SYMBOLS = {
     "mmf_attn_net_forward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mmf_attn_net_backward": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                         C.POINTER(AmilGrads), C.c_void_p]),
+    "mmf_linear_forward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "mmf_linear_forward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                     C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
     "mmf_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "mmf_linear_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

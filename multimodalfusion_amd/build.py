@@ -62,6 +62,21 @@ def build(force: bool = False, keep_temps: bool = False, verbose: bool = True) -
                     sys.stderr.write(r.stderr)
                 if r.returncode != 0:
                     raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stderr[-4000:])
+    if keep_temps:
+        # static checks of the hand-synchronised kernels in the ISA just written (tools/isa_check.py): no instruction may touch
+        # the destination of a hand-issued load before its hand-placed wait, the waits must be covered by younger VM
+        # operations, no scratch beside a hand-counted queue, no packed-fp32 VALU in the two units built without SLP
+        tools = os.path.join(os.path.dirname(HERE), "tools")
+        if os.path.exists(os.path.join(tools, "isa_check.py")):
+            sys.path.insert(0, tools)
+            import isa_check
+            units = [os.path.join(OBJ, u + "-hip-amdgcn-amd-amdhsa-gfx950.s") for u in ("mmf_amil_bf16_fwd2", "mmf_amil_bf16_dh2")]
+            bad = []
+            for u in units:
+                if os.path.exists(u):
+                    bad += isa_check.check_file(u, verbose=verbose)
+            if bad:
+                raise RuntimeError("ISA check failed:\n  " + "\n  ".join(bad))
     if jobs or force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1313,7 +1313,7 @@ static int launch_bwd_dh_wide(BwdDhParams p, hipStream_t st) {
 
 // > 0: the wide path will be taken and the kernel does K-prep itself, writing that many dbc partials
 static inline bool dh_short_grid(int64_t N, int H, int split = 0) {       // the 64x64 tiles on a grid of at most 512 workgroups
-  static const int cap = tune_int("MMF_DH_SHORT_MAX", 512);   // tuning override
+  static const int cap = tune_int("MMF_DH_SHORT_MAX", 1024);   // tuning override (round 4, 10k-14k bags: K-prep inside the 64 x 64 tiles, +5.4 us, against its own launch, 9.7 us)
   return !use_wide_tiles(N, H, split) && (N / 128) * ((H + 127) / 128) < 256 && ((N + 63) / 64) * ((H + 63) / 64) <= cap;
 }
 // the split-operand mode's 64 x 64 K-dh tiles: every bag below its wide tiles
@@ -1326,7 +1326,9 @@ bool bwd_dh_split_ok(int64_t N, int H, int D, int gated, int split) {
 }
 int bwd_dh_split_rows(int64_t N) { (void)N; return 224; }
 
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split) {
+// K-dh's tallest tile: the 240-row tile of the training variant (gated, relu bits) spills 28 registers (112 B per lane)
+constexpr int DH_MAX_ROWS = 224;
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split, int concurrent) {
   static const int env = tune_int("MMF_FUSED_PREP", 1);
   if (!env) return 0;
   // short grids: every column tile redoes K-prep for its 64 rows (64 KB of h) -- cheaper than a launch of its own
@@ -1334,7 +1336,7 @@ int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int 
   if (dh_short_grid(N, H, sm)) return (int)((N + 63) / 64);
   if (sm || !use_wide_tiles(N, H, split)) return 0;
   if (bwd_dh_split_ok(N, H, D, gated, split)) return (int)((N + bwd_dh_split_rows(N) - 1) / bwd_dh_split_rows(N));
-  const int rows = pick_wide_rows(N, H / 256, allow_half != 0);   // the fused launch always has the forward's relu bits
+  const int rows = pick_wide_rows(N, H / 256, allow_half != 0, concurrent != 0, DH_MAX_ROWS);   // the fused launch always has the forward's relu bits
   return (int)((N + rows - 1) / rows);
 }
 
@@ -1383,12 +1385,11 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
     return launch_bwd_dh_split_small(p, st);
   if (use_wide_tiles(p.N, p.H, p.split)) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
-    switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits)) {
-      case 48: return launch_bwd_dh_wide<48>(p, st);
-      case 64: return launch_bwd_dh_wide<64>(p, st);
-      case 128: return launch_bwd_dh_wide<128>(p, st);
-      case 192: return launch_bwd_dh_wide<192>(p, st);
-      case 208: return launch_bwd_dh_wide<208>(p, st);
+    switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits, p.concurrent != 0, DH_MAX_ROWS)) {
+#define MMF_WIDE_CASE(R) case R: return launch_bwd_dh_wide<R>(p, st);
+      MMF_WIDE_CASE(48) MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
+      MMF_WIDE_CASE(144) MMF_WIDE_CASE(160) MMF_WIDE_CASE(176) MMF_WIDE_CASE(192) MMF_WIDE_CASE(208)
+#undef MMF_WIDE_CASE
       default: return launch_bwd_dh_wide<224>(p, st);
     }
   }

@@ -35,9 +35,17 @@ __device__ inline float apply_act(float v, int act) {
 // `if (p.drop_p > 0)` inside the element loop the tile's 448 elements per lane each went through three scalar
 // branches (every taken branch refills the instruction buffer); the kernel dispatches ONCE per workgroup instead.
 // ACT = -1: any activation, decided per element (the rarely used tanh / sigmoid / SELU projections).
+// K-split launches: where the last-arriving workgroup of a tile finds the tile's partial sums (LinearParams::kpart)
+struct PartSrc {
+  rsrc_t rs;            // the whole kpart buffer
+  unsigned base;        // byte offset of this tile's first partial
+  unsigned slab;        // bytes per partial tile (BM x BN floats)
+  int S;                // partials per tile
+};
+
 template <class T, int ACT, bool DROP>
 __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], f32x4acc (*acch)[2], float* lds,
-                                       int row0, int col0) {
+                                       int row0, int col0, const PartSrc* ps = nullptr) {
 #ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
   {
     float t = 0.f;
@@ -96,6 +104,46 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
       if ((int64_t)rb16 * 16 < p.M && (int)(cb * 32) < p.N) p.relu_bits[(rb16 * (size_t)(p.N >> 5) + cb) * 8 + (lane & 7)] = mine;
     }
   };
+  if (ps) {
+    // the tile's sum comes from memory, already row-major: partial s of the tile, rows r + 8 t, columns c .. c + 3 of this
+    // lane -- added in split order (bit-reproducible); the loads of block b + 1 are issued before block b's stores
+    const int wave = threadIdx.x >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    const int rr = lane >> 3, c4 = lane & 7;
+    constexpr int NBLK = T::MB * T::NB;
+    float4 buf[2][4];
+    auto fetch = [&](int b, int rows4, float4 (&v)[4]) {
+      const int mb = b / T::NB, nb = b % T::NB;
+      const int r = wm * (T::BM / T::WM) + mb * 32 + rr, c = (wn * T::NB + nb) * 32 + 4 * c4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t >= rows4) break;
+        const unsigned o = ps->base + (unsigned)((r + 8 * t) * T::BN + c) * 4u;
+        float4 a = bld4_dev(ps->rs, o, 0);
+        for (int k = 1; k < ps->S; ++k) {
+          const float4 q = bld4_dev(ps->rs, o, (unsigned)k * ps->slab);
+          a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        }
+        v[t] = a;
+      }
+    };
+    fetch(0, 4, buf[0]);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int mb = b / T::NB, nb = b % T::NB;
+      if (b + 1 < NBLK) fetch(b + 1, 4, buf[(b + 1) & 1]);
+      else if constexpr (T::HALF) fetch(T::MB * T::NB, 2, buf[(b + 1) & 1]);
+      rows_op(std::integral_constant<int, 4>{}, nb, wm * (T::BM / T::WM) + mb * 32 + rr, (wn * T::NB + nb) * 32 + 4 * c4, buf[b & 1]);
+    }
+    if constexpr (T::HALF) {
+#pragma unroll
+      for (int nb = 0; nb < T::NB; ++nb) {
+        if (nb + 1 < T::NB) fetch(T::MB * T::NB + nb + 1, 2, buf[(NBLK + nb + 1) & 1]);
+        rows_op(std::integral_constant<int, 2>{}, nb, wm * (T::BM / T::WM) + T::MB * 32 + rr, (wn * T::NB + nb) * 32 + 4 * c4,
+                buf[(NBLK + nb) & 1]);
+      }
+    }
+    return;
+  }
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
     rows_op(std::integral_constant<int, 4>{}, nb, r, c, v);
   });
@@ -112,42 +160,92 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
   }
 }
 
+// K-split: this workgroup's accumulators -> its partial tile (device-scope stores), then a ticket.  Returns true for the
+// workgroup that arrived LAST at the tile (all partials are in memory then): it runs the epilogue from the partials.
+template <class T>
+__device__ inline bool ksplit_publish(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], f32x4acc (*acch)[2], float* lds,
+                                      int tile, int ks, PartSrc& ps) {
+  const int S = p.ksplit;
+  ps.rs = make_rsrc(p.kpart, (unsigned)((size_t)p.mt_count * p.nt_count * S * T::BM * T::BN * 4u));
+  ps.slab = (unsigned)(T::BM * T::BN * 4);
+  ps.base = (unsigned)tile * (unsigned)S * ps.slab;
+  ps.S = S;
+  const unsigned mine = ps.base + (unsigned)ks * ps.slab;
+  epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bst4_dev(ps.rs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
+  });
+  if constexpr (T::HALF) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / T::WN, wn = wave % T::WN;
+    float* blk = lds + wave * (32 * EPI_STRIDE);
+#pragma unroll
+    for (int nb = 0; nb < T::NB; ++nb) {
+      float4 v[2];
+      transpose_half(acch[nb][0], acch[nb][1], blk, lane, v);
+      const int r = wm * (T::BM / T::WM) + T::MB * 32 + (lane >> 3), c = (wn * T::NB + nb) * 32 + 4 * (lane & 7);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bst4_dev(ps.rs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial rows have reached device scope
+  __syncthreads();                                        // ... and every wave's
+  unsigned* flag = reinterpret_cast<unsigned*>(lds + (T::NT / 64) * 32 * EPI_STRIDE);     // behind the transpose scratch
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(p.ktick + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)(S - 1)) __hip_atomic_store(p.ktick + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // left zero for the next launch
+    flag[0] = old;
+  }
+  __syncthreads();
+  return flag[0] == (unsigned)(S - 1);
+}
+
 template <class T>
 __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
   extern __shared__ __align__(16) float lds[];
   MMF_KSTAMP(kernel_t0);
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count, mt, nt)) return;
+  const int S = p.ksplit > 1 ? p.ksplit : 1;
+  int mt, ntk;
+  // the (column tile, K split) pairs of one row tile are 8 workgroups apart: one XCD, whose L2 serves the shared x rows
+  if (!tile_of_block(blockIdx.x, p.mt_count, p.nt_count * S, mt, ntk)) return;
+  const int nt = ntk % p.nt_count, ks = ntk / p.nt_count;
   const int row0 = mt * T::BM, col0 = nt * T::BN;
+  const int nk = p.K / KC / S;
 
   LoadK<T::BM, T::NT> la;
   la.init_segments(p.x, p.nseg, p.kseg, p.ldx, row0, (int)p.M);
   LoadK<T::BN, T::NT> lb;
   lb.init(p.w, p.K, col0, p.N);
+  la.kt0 = lb.kt0 = ks * nk;
 
   f32x16 acc[T::MB][T::NB];
   f32x4acc acch[T::NB][2];                   // the half block's accumulators (Tile::HALF; unused otherwise)
   MMF_KSTAMP(k0);
   if constexpr (T::NT == 256 && T::BM <= 64) {
-    if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, p.K / KC, lds, acc);      // short grid: see gemm_mainloop_deep
-    else gemm_mainloop<T>(la, lb, p.K / KC, lds, acc);
+    if (p.deep) gemm_mainloop_deep<T, 4>(la, lb, nk, lds, acc);      // short grid: see gemm_mainloop_deep
+    else gemm_mainloop<T>(la, lb, nk, lds, acc);
   } else {
-    gemm_mainloop<T>(la, lb, p.K / KC, lds, acc, acch);
+    gemm_mainloop<T>(la, lb, nk, lds, acc, acch);
   }
   MMF_KSTAMP(k1);
 #ifdef MMF_STAMPS
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], k0 - kernel_t0);     // entry -> loaders initialised
 #endif
+  PartSrc part;
+  const PartSrc* ps = nullptr;
+  if (S > 1) {
+    if (!ksplit_publish<T>(p, acc, acch, lds, mt * p.nt_count + nt, ks, part)) return;
+    ps = &part;
+  }
   const bool drop = p.drop_p > 0.f;
   if (p.act == ACT_RELU) {
-    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, acch, lds, row0, col0);
-    else linear_epilogue<T, ACT_RELU, false>(p, acc, acch, lds, row0, col0);
+    if (drop) linear_epilogue<T, ACT_RELU, true>(p, acc, acch, lds, row0, col0, ps);
+    else linear_epilogue<T, ACT_RELU, false>(p, acc, acch, lds, row0, col0, ps);
   } else if (p.act == ACT_NONE && !drop) {
-    linear_epilogue<T, ACT_NONE, false>(p, acc, acch, lds, row0, col0);
+    linear_epilogue<T, ACT_NONE, false>(p, acc, acch, lds, row0, col0, ps);
   } else if (drop) {
-    linear_epilogue<T, -1, true>(p, acc, acch, lds, row0, col0);
+    linear_epilogue<T, -1, true>(p, acc, acch, lds, row0, col0, ps);
   } else {
-    linear_epilogue<T, -1, false>(p, acc, acch, lds, row0, col0);
+    linear_epilogue<T, -1, false>(p, acc, acch, lds, row0, col0, ps);
   }
 #ifdef MMF_STAMPS
   MMF_KSTAMP(k2);
@@ -702,18 +800,24 @@ static inline bool use_big_tiles(int64_t M, int N) { return (M / 128) * ((N + 12
 template <int ROWS>
 using TileW = Tile<ROWS, 256, 1, 8, true, true>;
 
-// tile height that minimises rounds x blocks over the 256 CUs (0.35: per-tile prologue / epilogue, in 32-row blocks);
-// 208 = six blocks + a 16-row half block (Tile::HALF): a 50k bag becomes 241 tiles on 241 CUs instead of 224
-int pick_wide_rows(int64_t M, int ntn, bool allow_half) {
+// tile height that minimises rounds x blocks over the 256 CUs (0.35: per-tile prologue / epilogue, in 32-row blocks).
+// Heights are the multiples of 16 from 64 to 240 rows; an odd multiple ends with a 16-row half block (Tile::HALF):
+// 208 rows put a 50k bag on 241 CUs instead of 224, 96 rows a 24k bag on 250 instead of 188 (128 rows), 160 rows a 40k
+// bag on 250 instead of 209 (192), 240 rows a 60k bag on 250 in ONE round instead of 289 tiles of 208 rows in two.
+// 256 rows need > 256 VGPRs with double-buffered fragments (spills).
+// concurrent (mmf_amil_desc::concurrent: other bags' kernels run beside this one): plan for 224 of the 256 CUs, which
+// keeps the measured choice at 50k (224 tiles of 224 rows; 1376 vs 1337 bags/s with 208-row tiles and bags in flight)
+// and, unlike the former "no half blocks when concurrent", does not push a 60k bag into two rounds of 224-row tiles.
+int pick_wide_rows(int64_t M, int ntn, bool allow_half, bool concurrent, int max_rows) {
   static const int env = tune_int("MMF_WIDE_ROWS", 0);   // tuning override
-  if (env > 0 && ((env != 208 && env != 48) || allow_half)) return env;
+  if (env > 0 && (env % 32 == 0 || allow_half)) return env;
+  const int cus = concurrent ? 224 : 256;
   int best = 224;
   double bestc = 1e30;
-  const int cand[5] = {224, 208, 192, 128, 64};   // 256 rows need > 256 VGPRs with double-buffered fragments (spills)
-  for (int rows : cand) {
-    if (rows == 208 && !allow_half) continue;
+  for (int rows = max_rows; rows >= 64; rows -= 16) {
+    if (rows % 32 != 0 && !allow_half) continue;
     int64_t tiles = ((M + rows - 1) / rows) * ntn;
-    int64_t rounds = (tiles + 255) / 256;
+    int64_t rounds = (tiles + cus - 1) / cus;
     double c = (double)rounds * (rows / 32.0 + 0.35);
     if (c < bestc) { bestc = c; best = rows; }
   }
@@ -751,6 +855,30 @@ static int launch_linear_split(LinearParams p, hipStream_t st) {
   return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
 }
 
+// K split of the 64 x 64 projection tiles on short grids (LinearParams::ksplit).  A bag of 1,000 instances is 64 tiles, each
+// a serial loop over 32 k-chunks (~25 us whatever the tile does: one MFMA block per wave and chunk), on 256 CUs; the radio
+// head's reduce_dim (M = 512, K = 4 x 1024) is 128 tiles of 128 chunks.  Split S ways they are S times as many workgroups with
+// loops 1 / S as long; the partial tiles (S x M x N floats) cross L2 / Infinity Cache once each way.
+int linear_ksplit(int64_t M, int N, int K, int nseg, int kseg) {
+  static const int max_wg = tune_int("MMF_KSPLIT_MAX_WG", 512);     // tuning override: 0 = never split
+  if (M <= 0 || N % 4 != 0 || K % KC != 0 || use_wide_tiles(M, N, 0) || use_big_tiles(M, N)) return 1;
+  const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  const int nk = K / KC;
+  if (nseg > 1 && (kseg % (4 * KC) != 0)) return 1;
+  // measured (round 4, path bags, projection kernel us unsplit -> split): 512 rows 25.4 -> 23.2, 1,000 26.4 -> 20.3, 2,000
+  // 26.5 -> 24.5, 4,096 (256 tiles, two ways) 26.4 -> 29.3: from one tile per CU on, splitting only adds the partial traffic
+  static const int max_tiles = tune_int("MMF_KSPLIT_MAX_TILES", 128);
+  if (tiles > max_tiles) return 1;
+  for (int S = 4; S >= 2; S -= 2)
+    if (tiles * S <= max_wg && nk % (4 * S) == 0 && nk / S >= 8) return S;
+  return 1;
+}
+size_t linear_ksplit_floats(int64_t M, int N, int K, int nseg, int kseg) {
+  const int S = linear_ksplit(M, N, K, nseg, kseg);
+  if (S <= 1) return 0;
+  return (size_t)S * (size_t)((M + 63) / 64) * (size_t)((N + 63) / 64) * 64 * 64;
+}
+
 int launch_linear(LinearParams p, hipStream_t st) {
   if (p.K % KC != 0 || (p.nseg > 1 && p.kseg % KC != 0)) return MMF_ERR_SHAPE;
   if (p.ldx % 4 != 0) return MMF_ERR_ALIGN;
@@ -765,12 +893,11 @@ int launch_linear(LinearParams p, hipStream_t st) {
     return launch_linear_split<224, 1, 8>(p, st);
   }
   if (use_wide_tiles(p.M, p.N, can_split)) {
-    switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0)) {
-      case 48: return launch_linear_wide<48>(p, st);
-      case 64: return launch_linear_wide<64>(p, st);
-      case 128: return launch_linear_wide<128>(p, st);
-      case 192: return launch_linear_wide<192>(p, st);
-      case 208: return launch_linear_wide<208>(p, st);
+    switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0, p.concurrent != 0, 240)) {
+#define MMF_WIDE_CASE(R) case R: return launch_linear_wide<R>(p, st);
+      MMF_WIDE_CASE(48) MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
+      MMF_WIDE_CASE(144) MMF_WIDE_CASE(160) MMF_WIDE_CASE(176) MMF_WIDE_CASE(192) MMF_WIDE_CASE(208) MMF_WIDE_CASE(240)
+#undef MMF_WIDE_CASE
       default: return launch_linear_wide<224>(p, st);
     }
   }
@@ -782,6 +909,14 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (can_split && p.M >= split_min_rows()) {
     using T = TileSp<64, 64, 2, 2>;
     return launch_tiled<T>("linear_nt_split_kernel", linear_nt_split_kernel<T>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
+  }
+  {
+    const int S = (p.kpart && p.ktick) ? linear_ksplit(p.M, p.N, p.K, p.nseg, p.kseg) : 1;
+    if (S > 1 && p.mt_count * p.nt_count <= p.ktick_words) {
+      p.ksplit = S;
+      p.deep = short_grid((int64_t)p.mt_count * p.nt_count * S) ? 1 : 0;        // (K / KC / S) % 4 == 0 by linear_ksplit
+      return launch_tiled<TileNT64>("linear_nt_kernel", linear_nt_kernel<TileNT64>, p, grid_for_tiles(p.mt_count, p.nt_count * S), st);
+    }
   }
   // a segmented (radio: M = 512, K = 4 x 1024) or otherwise long-K projection on <= 128 workgroups leaves half the CUs
   // idle for the whole K loop: half-height tiles (two waves) put it on twice as many
@@ -823,7 +958,11 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st) {
     return q.gated ? launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, true>, q, grid, st)
                    : launch_tiled<TS>("gate_fwd_kernel", gate_fwd_kernel<TS, false>, q, grid, st);
   };
-  const bool big = (p.N / 128) * p.nt_count >= 256;
+  // 128-row tiles only once they fill most of the 512 slots (two workgroups per CU): a 10k bag is 316 tall tiles -- every
+  // CU busy for a tall tile's time, 60 of them twice -- or 628 short ones in 1.2 rounds: measured 40.6 vs 35.1 us (round 4,
+  // tools/r4_mid_try.sh; 12,288 rows: 40.3 vs 35.3; from 12,800 rows the tall tiles win, 14k: 41.0 vs 44.0)
+  static const int big_min = tune_int("MMF_GATE_BIG_MIN", 400);
+  const bool big = (p.N / 128) * p.nt_count >= big_min;
   if (!big) return small(p);
   // 128x128 tiles run two per CU: 512 slots.  Two things cost this launch time: a sparse last round (a 50k bag is
   // 1564 tiles = 3 rounds + 28 tiles, which cost most of a 4th round: 132 us against 116 us for the 1536 tiles of

@@ -86,6 +86,7 @@ struct AmilWs {
   unsigned long long* relu_bits;     // [ceil(N/16)][H/32][8]: h > 0 per element (LinearParams::relu_bits)
   float *h, *a, *b, *s_part, *partials, *stats, *p, *ds, *dbc_part, *du;
   float *slab_w1, *slab_wab, *cs_b1, *cs_bab, *cs_wc;
+  float* kpart;                      // partial tiles of a K-split projection (LinearParams::kpart), or null
   int parts, groups, splits, k_per_split, mstk, tile;
   int splits_g, k_per_split_g;      // K split of the gate problem (d[Wa;Wb]): more, shorter splits than dW1
   size_t bytes;
@@ -140,6 +141,10 @@ static AmilWs carve(void* base, int64_t N, int L, int H, int D, int gated, bool 
   w.s_part = take((size_t)w.parts * N);
   w.partials = take((size_t)w.groups * (2 + H));
   w.stats = take(4);
+  {
+    const size_t kf = linear_ksplit_floats(N, H, L, 1, L);
+    w.kpart = kf ? take(kf) : nullptr;
+  }
   if (infer) {            // forward-only: nothing is kept for a backward (a, b stay null: K-gate skips their stores)
     w.bytes = off;
     return w;
@@ -250,7 +255,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 9; }
+int mmf_abi_version(void) { return 10; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -288,8 +293,9 @@ static int amil_forward_impl(const mmf_amil_desc* d, const float* x, void* works
   lp.M = d->N; lp.N = d->H; lp.K = d->L;
   lp.act = ACT_RELU; lp.drop_p = d->p_h; lp.drop_key = drop_key(d->seed, 0); lp.seed_dev = seed_dev;
   lp.relu_bits = infer ? nullptr : w.relu_bits;
-  lp.allow_half = d->concurrent ? 0 : 1;
+  lp.allow_half = 1; lp.concurrent = d->concurrent ? 1 : 0;
   lp.split = d->gemm == MMF_GEMM_BF16X3;
+  lp.kpart = w.kpart; lp.ktick = d->sync; lp.ktick_words = d->sync ? d->sync_words : 0;
   if (int e = launch_linear(lp, st)) return e;
 
   GateFwdParams gp{};
@@ -346,12 +352,12 @@ static int amil_backward_impl(const mmf_amil_desc* d, const float* x, void* work
   BwdDhParams dp{};
   dp.g = gc; dp.Wa = d->Wa; dp.Wb = d->Wb; dp.p = w.p; dp.dM = dM; dp.h = w.h; dp.du = w.du;
   dp.relu_bits = w.relu_bits;
-  dp.allow_half = d->concurrent ? 0 : 1;
+  dp.allow_half = 1; dp.concurrent = d->concurrent ? 1 : 0;
   dp.split = d->gemm == MMF_GEMM_BF16X3;
   dp.N = d->N; dp.H = d->H; dp.scale_h = d->p_h > 0.f ? 1.0f / (1.0f - d->p_h) : 1.0f;
 
   // K-prep (softmax weights, ds) either fused into the wide K-dh kernel or as its own launch
-  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, d->concurrent ? 0 : 1, d->D, d->gated, dp.split);
+  int dbc_groups = bwd_dh_fused_groups(d->N, d->H, 1, d->D, d->gated, dp.split, d->concurrent ? 1 : 0);
   if (dbc_groups > 0 && dbc_groups <= PREP_GROUPS) {
     dp.fused_prep = 1;
     dp.A_raw = A_raw; dp.stats = w.stats; dp.Mpool = M; dp.gA = gA;
@@ -736,10 +742,15 @@ int mmf_attn_net_backward(const mmf_amil_desc* d, const float* x, void* workspac
   return launch_reduce(rp, st);
 }
 
+size_t mmf_linear_forward_workspace_bytes(int64_t M, int32_t N, int32_t nseg, int32_t kseg) {
+  if (nseg < 1 || nseg > 4 || kseg < 1) return 0;
+  return linear_ksplit_floats(M, N, nseg * kseg, nseg, kseg) * sizeof(float);
+}
+
 int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, int64_t M,
                        const float* W, const float* bias, int32_t N, int32_t act,
                        float drop_p, uint32_t drop_seed, uint32_t drop_site, const uint32_t* seed_dev,
-                       float* y, void* stream) {
+                       float* y, void* workspace, size_t workspace_bytes, uint32_t* sync, int32_t sync_words, void* stream) {
   if (!x_segs || nseg < 1 || nseg > 4 || !W || !y) return MMF_ERR_ARG;
   if (act < 0 || act > ACT_SELU || drop_p < 0.f || drop_p >= 1.f) return MMF_ERR_ARG;
   if (M * (int64_t)kseg * 4 >= (int64_t)1 << 31 || (int64_t)N * nseg * kseg * 4 >= (int64_t)1 << 31) return MMF_ERR_SHAPE;
@@ -753,6 +764,10 @@ int mmf_linear_forward(const float* const* x_segs, int32_t nseg, int32_t kseg, i
   lp.nseg = nseg; lp.kseg = kseg; lp.ldx = kseg;
   lp.w = W; lp.bias = bias; lp.y = y; lp.M = M; lp.N = N; lp.K = nseg * kseg;
   lp.act = act; lp.drop_p = drop_p; lp.drop_key = drop_key(drop_seed, drop_site); lp.seed_dev = seed_dev;
+  if (workspace && sync && sync_words > 0 && aligned16(workspace) &&
+      workspace_bytes >= linear_ksplit_floats(M, N, lp.K, nseg, kseg) * sizeof(float) && workspace_bytes > 0) {
+    lp.kpart = static_cast<float*>(workspace); lp.ktick = sync; lp.ktick_words = sync_words;
+  }
   return launch_linear(lp, static_cast<hipStream_t>(stream));
 }
 

@@ -113,6 +113,19 @@ __device__ inline float4 bld4(rsrc_t r, unsigned voff, unsigned soff) {
   f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
   return f;
 }
+// The same with DEVICE scope (sc1): what one workgroup stores this way, a workgroup on ANOTHER XCD reads back this way
+// (the XCDs' L2s are not coherent with each other for plain accesses; LLVM's gfx942 memory model spells an agent-scope
+// atomic load / store as exactly this bit).  Used for the K-split partial tiles, nothing else.
+__device__ inline float4 bld4_dev(rsrc_t r, unsigned voff, unsigned soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 16);
+  float4 f;
+  f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w);
+  return f;
+}
+__device__ inline void bst4_dev(rsrc_t r, unsigned voff, unsigned soff, const float4& f) {
+  u32x4 v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 16);
+}
 __device__ inline float bld1(rsrc_t r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
@@ -126,6 +139,7 @@ struct LoadK {
   using Map = KMap<ROWS, NT>;
   rsrc_t r0, r1, r2, r3;
   int kseg, tid;
+  int kt0 = 0;                 // first chunk of this workgroup's K range (K-split launches; 0 otherwise)
   unsigned voff[Map::NV];
   float4 r[Map::NV];
   __device__ inline void set_offsets(int ld, int row0, int nrows) {
@@ -151,7 +165,7 @@ struct LoadK {
     set_offsets(ld, row0, nrows);
   }
   __device__ inline void load(int kt) {
-    const int k0 = kt * KC;
+    const int k0 = (kt + kt0) * KC;
     const int sidx = k0 / kseg;
     const rsrc_t rs = sidx == 0 ? r0 : (sidx == 1 ? r1 : (sidx == 2 ? r2 : r3));
     const unsigned soff = (unsigned)(k0 - sidx * kseg) * 4u;
@@ -167,7 +181,7 @@ struct LoadK {
   static constexpr bool kHalves = true;
   static constexpr int HV = Map::NV / 2;
   __device__ inline void load_half(int kt, int h) {
-    const int k0 = kt * KC;
+    const int k0 = (kt + kt0) * KC;
     const int sidx = k0 / kseg;
     const rsrc_t rs = sidx == 0 ? r0 : (sidx == 1 ? r1 : (sidx == 2 ? r2 : r3));
     const unsigned soff = (unsigned)(k0 - sidx * kseg) * 4u;

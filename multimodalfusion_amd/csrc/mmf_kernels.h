@@ -29,10 +29,23 @@ struct LinearParams {      // y[M x N] = drop(act(concat_k(x_s)[M x K] . W[N x K
   // 16-row block): rows rr + 8 t with t = 0, 1 go to bit block rb16 as word 4 t + e, t = 2, 3 to rb16 + 1 as word
   // 4 (t - 2) + e.  bits[(rb16 * (N / 32) + cb) * 8 + word].  Needs N % 32 == 0 and tile rows that are multiples of 16.
   unsigned long long* relu_bits;
-  int allow_half;          // 1: the 208-row half-block tile may be chosen (the stack's projection with mmf_amil_desc::concurrent == 0)
+  int allow_half;          // 1: tile heights that end with a 16-row half block may be chosen (the stack's projection)
+  int concurrent;          // mmf_amil_desc::concurrent: plan the wide tiles for 224 of the 256 CUs
   int deep;                // set by launch_linear: short grid, use the deep-prefetch main loop
   int split;               // 1: the split-operand core (mmf_gemm_split.h) where the shape has a tile for it
+  // K-split (short grids: a few dozen tiles, each a long serial K loop, on 256 CUs): `ksplit` workgroups share an output tile,
+  // each contracts 1 / ksplit of K and writes its partial tile to kpart[(tile * ksplit + s)][BM x BN] with device-scope
+  // stores; the LAST to arrive (ktick[tile]: a device-scope counter, zero before the launch and left zero by it) sums the
+  // partials in split order -- deterministic -- and runs the epilogue.  No workgroup ever waits for another.
+  // launch_linear sets ksplit from linear_ksplit() when kpart / ktick are given; 1 otherwise.
+  int ksplit;
+  float* kpart;
+  unsigned* ktick;
+  int ktick_words;
 };
+// K split launch_linear will use for this shape when it is given partial-tile space and tick words; 1 = none
+int linear_ksplit(int64_t M, int N, int K, int nseg, int kseg);
+size_t linear_ksplit_floats(int64_t M, int N, int K, int nseg, int kseg);   // size of LinearParams::kpart (0: no split)
 
 struct GateFwdParams {
   const float* h;          // [N x H] (post ReLU/dropout)
@@ -166,7 +179,8 @@ struct BwdDhParams {       // du = (dP.Wab + p dM) * relu'(h) * scale_h
   float scale_h;           // 1/(1-p_h) in train mode, 1 in eval
   int mt_count, nt_count;
   int deep;                // set by launch_bwd_dh: short grid, deep-prefetch main loop (dh_mainloop_deep)
-  int allow_half;          // 1: the 208-row half-block tile may be chosen (needs fused_prep, relu_bits, concurrent == 0)
+  int allow_half;          // 1: half-block tile heights may be chosen (needs fused_prep and relu_bits)
+  int concurrent;          // mmf_amil_desc::concurrent
   int split;               // 1: the split-operand core (mmf_gemm_split.h): gated stacks with fused K-prep on wide tiles
   // fused prep (wide tiles own whole rows of h): the kernel computes p_i, ds_i itself (K-prep's job), keeps them
   // in LDS for its loader / epilogue and publishes them for the TN kernel
@@ -229,10 +243,10 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st);
 // split-operand mode on bags below the wide tiles: instances from which the small split tiles (64-row GEMM tiles, 128 x 128
 // TN tile) are taken instead of the exact-fp32 ones (default 1: every bag, which keeps an instance's score independent of its bag's size)
 int split_min_rows();
-int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
+int bwd_dh_fused_groups(int64_t N, int H, int allow_half, int D, int gated, int split, int concurrent);   // > 0: launch_bwd_dh computes p/ds itself and writes that many dbc partials
 int launch_tn(TnParams p, hipStream_t st);
 // wide (32*MB x 256, one 8-wave workgroup per CU) tile selection, shared by the row-parallel GEMMs
-int pick_wide_rows(int64_t M, int ntn, bool allow_half);
+int pick_wide_rows(int64_t M, int ntn, bool allow_half, bool concurrent, int max_rows);
 bool use_wide_tiles(int64_t M, int N, int split = 0);   // split: the bf16x3 mode's (later) crossover
 // split-K plan shared by the workspace carving and the launcher
 int tn_tile_dim(int64_t K, int D_gate);                    // 256: one 8-wave 256x256 workgroup per CU; else 128

@@ -51,8 +51,18 @@ class DeviceSeed:
 class GraphedStep:
     def __init__(self, fn, warmup: int = 3, seed0: int = 0):
         self.seed = DeviceSeed(seed0)
+        # the graph's own tick words (mmf_amil_desc::sync): replays of this graph are ordered among themselves, but may
+        # overlap other streams' calls, so it shares them with nobody
+        self.sync = torch.zeros(ops.SYNC_WORDS, dtype=torch.int32, device=self.seed.word.device)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        prev_sync = ops.set_sync_override(self.sync)
+        try:
+            self._build(fn, warmup, s)
+        finally:
+            ops.set_sync_override(prev_sync)
+
+    def _build(self, fn, warmup, s):
         with self.seed:                          # the word is passed to the launches made in here, nowhere else
             with torch.cuda.stream(s):           # warm-up off the default stream (allocator pools, LDS attributes)
                 for _ in range(warmup):

@@ -56,8 +56,43 @@ def set_trace(handle):
     return prev
 
 
+SYNC_WORDS = 1024
+_sync = {}
+_sync_override = None
+
+
+def set_sync_override(words):
+    """words: zeroed int32 CUDA tensor [SYNC_WORDS] that every call made from now on uses, or None.  Returns the previous one.
+    graph.GraphedStep gives each captured graph its own (replays of two graphs may overlap on different streams)."""
+    global _sync_override
+    prev, _sync_override = _sync_override, words
+    return prev
+
+
+def sync_words(device=None):
+    """The tick words of mmf_amil_desc::sync for calls issued on the CURRENT stream of `device`: one zeroed int32 tensor per
+    (device, stream), made once and kept -- every call leaves the words zero, and calls that may overlap (other streams: bags in
+    flight) get their own.  None while a stream is being captured without an override (the calls then run unsplit)."""
+    if _sync_override is not None:
+        return _sync_override
+    if (device is not None and torch.device(device).type != "cuda") or not torch.cuda.is_available():
+        return None                      # CPU tensors: the call itself raises MmfError (there is no CPU path)
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _sync.get(key)
+    if t is None:
+        t = _sync[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=dev)
+    return t
+
+
 def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, seed_word):
-    return AmilDesc(N=N, L=L, H=H, D=D, gated=1 if gated else 0,
+    sw = sync_words(W1.device if W1 is not None else None)
+    return AmilDesc(sync=ptr(sw), sync_words=SYNC_WORDS if sw is not None else 0,
+                    N=N, L=L, H=H, D=D, gated=1 if gated else 0,
                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF,
@@ -372,8 +407,12 @@ class LinearCatFn(torch.autograd.Function):
             raise _lib.MmfError("weight does not match the concatenated width")
         y = torch.empty((M, N), dtype=torch.float32, device=W.device)
         segs = (C.c_void_p * nseg)(*[ptr(x) for x in xs])
+        wsb = lib().mmf_linear_forward_workspace_bytes(M, N, nseg, kseg)
+        sw = sync_words(W.device) if wsb else None
+        ws = torch.empty(wsb, dtype=torch.uint8, device=W.device) if sw is not None else None
         check(lib().mmf_linear_forward(segs, nseg, kseg, M, ptr(W), ptr(b), N, ACT["none"], 0.0, 0, 0, None,
-                                       ptr(y), stream_ptr()), "mmf_linear_forward")
+                                       ptr(y), ptr(ws), wsb if ws is not None else 0, ptr(sw), SYNC_WORDS if sw is not None else 0,
+                                       stream_ptr()), "mmf_linear_forward")
         ctx.save_for_backward(W, *xs)
         ctx.has_bias = b is not None
         return y

@@ -175,16 +175,26 @@ def test_mm_with_bf16_path_bag_tracks_the_fp32_run():
         assert err <= 0.15 * nrm + 1e-6, (k, err, nrm)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train", "train_attention_dropout"])
 @pytest.mark.parametrize("N", [100_000, 33_333])
-def test_bf16_step_is_bit_reproducible(N):
+def test_bf16_step_is_bit_reproducible(N, mode, monkeypatch):
     """Two 4-wave workgroups share a CU in the fused forward and in K-dh (second forms): any cross-wave race or missed hazard
     shows as a handful of differing elements in a few tiles of a few launches (round 3 found one that way: packed-fp32
     instructions in the fused forward, tools/f2_debug.py).  Scores and every gradient must be bit-identical over repeated
-    forward + backward passes (eval mode: no dropout seed involved)."""
+    forward + backward passes -- in eval mode (the <false> instantiations of the two kernels) and in train mode with a pinned
+    dropout seed, without and with attention dropout: the <true> instantiations that training and bench.py run (keep-bits
+    hashed inside the fused forward's main loop; K-dh's attention-dropout variant), alone and with two bags in flight."""
+    from multimodalfusion_amd import ops
     from multimodalfusion_amd.models import MIL_Attention_fc_surv_path
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
     torch.manual_seed(5)
-    model = MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=False, n_classes=4).to(DEV).eval()
+    model = MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=(mode == "train_attention_dropout"),
+                                       n_classes=4).to(DEV)
+    if mode == "eval":
+        model.eval()
+    else:
+        model.train()
+        monkeypatch.setattr(ops, "next_dropout_seed", lambda: 4242)      # the same masks in every pass
     x = torch.randn(N, 1024, device=DEV).to(torch.bfloat16)
     Y, c = torch.tensor([1], device=DEV), torch.tensor([0.0], device=DEV)
 
@@ -201,3 +211,26 @@ def test_bf16_step_is_bit_reproducible(N):
         cur = step()
         for k, (a, b) in enumerate(zip(cur, ref)):
             assert torch.equal(a, b), (i, k, int((a != b).sum()))
+    if mode == "train_attention_dropout":
+        return
+    # the same bag on two streams at once (a third and fourth workgroup compete for every CU): each stream's result must
+    # still be the single-stream result, bit for bit
+    streams = [torch.cuda.Stream(DEV) for _ in range(2)]
+    models = [model, MIL_Attention_fc_surv_path(gate_path=True, model_size_wsi="small", dropout=False, n_classes=4).to(DEV)]
+    models[1].load_state_dict(model.state_dict())
+    models[1].train(model.training)
+    for i in range(4):
+        outs = []
+        for st, mdl in zip(streams, models):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for p in mdl.parameters():
+                    p.grad = None
+                hz, S, Yh, A = mdl(path_features=x)
+                NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=Y, c=c).backward()
+                outs.append((A, mdl))
+        torch.cuda.synchronize()
+        for A, mdl in outs:
+            cur = [A.detach()] + [p.grad for p in mdl.parameters()]
+            for k, (a, b) in enumerate(zip(cur, ref)):
+                assert torch.equal(a, b), ("two streams", i, k, int((a != b).sum()))

@@ -84,7 +84,7 @@ def test_linear_forward_abi_all_activations_large(act, drop_p):
     segs = (C.c_void_p * 1)(tx.data_ptr())
     code = {"none": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}[act]
     rc = l.mmf_linear_forward(segs, 1, K, M, C.c_void_p(tW.data_ptr()), C.c_void_p(tb.data_ptr()), N, code,
-                              C.c_float(drop_p), seed, site, None, C.c_void_p(y.data_ptr()),
+                              C.c_float(drop_p), seed, site, None, C.c_void_p(y.data_ptr()), None, 0, None, 0,
                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()

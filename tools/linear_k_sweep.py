@@ -14,7 +14,7 @@ for K in (32, 64, 128, 256, 512, 1024):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
         return l.mmf_linear_forward(segs, 1, K, M, C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), N, 1, C.c_float(0.25), 7, 0, None,
-                                    C.c_void_p(y.data_ptr()), st)
+                                    C.c_void_p(y.data_ptr()), None, 0, None, 0, st)
     for _ in range(20): assert run() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,7 +9,7 @@ x = torch.randn(N, 1024, device="cuda"); W = torch.randn(256, 1024, device="cuda
 y = torch.empty(N, 256, device="cuda")
 segs = (C.c_void_p * 1)(x.data_ptr())
 def run():
-    rc = l.mmf_linear_forward(segs, 1, 1024, N, W.data_ptr(), b.data_ptr(), 256, 1, 0.25, 7, 0, None, y.data_ptr(), None)
+    rc = l.mmf_linear_forward(segs, 1, 1024, N, W.data_ptr(), b.data_ptr(), 256, 1, 0.25, 7, 0, None, y.data_ptr(), None, 0, None, 0, None)
     assert rc == 0
 for _ in range(3): run()
 torch.cuda.synchronize()
