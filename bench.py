@@ -505,8 +505,31 @@ def other_configs_leg(dev, steps, warmup, gen):
     # eager: event times arrive from the host every step (float64, pageable), as in the reference's loop; the captured step
     # reads them from a device-resident buffer (a copy from pageable memory cannot be captured)
     ot_dev = ot.to(dev)
-    out["config3_omic_maxnet_B128_cox"] = both(omic, {"genomic_features": rn(128, 36)}, lambda r: cox(risks=r[0], times=ot, c=oc),
-                                               lambda r: cox(risks=r[0], times=ot_dev, c=oc))
+    xo = rn(128, 36)
+    composable = both(omic, {"genomic_features": xo}, lambda r: cox(risks=r[0], times=ot, c=oc),
+                      lambda r: cox(risks=r[0], times=ot_dev, c=oc))
+    # what the training-loop mirror runs for this model (utils/core_utils.py: MaxNet.cox_step): forward + Cox + backward in
+    # ONE launch, event times device-resident; the composable path (3 dense + Cox + 3 dense-backward launches) beside it
+    for p in omic.parameters():
+        p.grad = torch.zeros_like(p)
+
+    def one_launch():
+        omic.cox_step(xo, ot_dev, oc, grad_out=[p.grad for p in omic.parameters()], accumulate=False)
+
+    res = timeit(one_launch)
+    from multimodalfusion_amd import _lib
+    torch.cuda.synchronize()
+    with _lib.KernelTrace(capacity=256) as tr:
+        for _ in range(20):
+            one_launch()
+        torch.cuda.synchronize()
+        prof = tr.dump()
+    tr.close()
+    res["kernel_us"] = {k: round(1e3 * ms / max(n, 1), 2) for k, (n, ms) in prof.items()}
+    res["composable"] = composable
+    out["config3_omic_maxnet_B128_cox"] = res
+    for p in omic.parameters():
+        p.grad = None
     del radio, omic
     for tag, n, dt in (("config4_mm_50k_f32", 50_000, torch.float32), ("config5_mm_100k_bf16", 100_000, torch.bfloat16)):
         xp = rn(n, 1024).to(dt)

@@ -281,6 +281,38 @@ int mmf_kron_backward(const float* g, const float* const* o, int32_t m, int32_t 
  *   covers (l1_reg_modules, utils/utils.py:259-268: fc_omic and mm only).
  * mmf_abs_sum: out[0] = sum_i |w_i| (the value of l1_reg_all); partials = 512 floats of scratch.
  * ------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Omic head, ONE training step in ONE launch:  MaxNet forward (two SNN blocks + classifier -> risk), CoxSurvLoss, and
+ * every parameter gradient.
+ *   replaces models/model_genomic.py:53-72 (MaxNet.forward, bag_loss = cox_surv), models/model_modules.py:64-68 (SNN_Block:
+ *   Linear + SELU + AlphaDropout), utils/loss_utils.py:124-139 (CoxSurvLoss) and the backward autograd derives from them --
+ *   ~20 framework launches in the reference, 9 through the composable entry points above (mmf_dense_*, mmf_cox_surv).
+ *   `small` net only (H0 = H1 = 256), B <= 256, G <= 256; other shapes: MMF_ERR_SHAPE (use the composable entry points).
+ *   times: DEVICE float64 [B] (the reference compares event times in float64); loss: unscaled; gradients are those of
+ *   loss * loss_scale, written or (accumulate) added.  Needs 3 tick words (mmf_amil_desc::sync's contract).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mmf_maxnet_desc {
+  int32_t B, G, H0, H1;      /* batch, input genes, hidden widths */
+  const float* x;            /* [B x G] */
+  const float* W0;           /* [H0 x G]  fc_omic.0.0.weight */
+  const float* b0;           /* [H0] */
+  const float* W1;           /* [H1 x H0] fc_omic.1.0.weight */
+  const float* b1;           /* [H1] */
+  const float* Wc;           /* [1 x H1]  classifier.weight */
+  const float* bc;           /* [1] */
+  float p_drop;              /* AlphaDropout probability of both blocks (0.25 in train mode, 0 in eval) */
+  uint32_t seed;             /* dropout seed: block i draws with site i, element index b * 256 + n (as mmf_dense_forward) */
+  const uint32_t* seed_dev;  /* optional device word added to the seed (graph replays), or NULL */
+  uint32_t* sync;            /* tick words, >= 3 */
+  int32_t sync_words;
+  struct mmf_trace* trace;
+} mmf_maxnet_desc;
+typedef struct mmf_maxnet_grads { float *dW0, *db0, *dW1, *db1, *dWc, *dbc; } mmf_maxnet_grads;
+size_t mmf_maxnet_cox_step_workspace_bytes(int32_t B);
+int mmf_maxnet_cox_step(const mmf_maxnet_desc* desc, const double* times, const float* c, float loss_scale,
+                        void* workspace, size_t workspace_bytes, float* risk, float* loss,
+                        const mmf_maxnet_grads* grads, int32_t accumulate, void* stream);
+
 int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float l1_coeff, const float* l1_mask, int32_t step, void* stream);
 int mmf_abs_sum(const float* w, int64_t n, float* partials, float* out, void* stream);

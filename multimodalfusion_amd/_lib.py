@@ -51,6 +51,19 @@ class NllTarget(C.Structure):
                 ("accumulate", C.c_int32)]
 
 
+class MaxnetDesc(C.Structure):
+    """struct mmf_maxnet_desc (include/mmf_amil.h)."""
+    _fields_ = [("B", C.c_int32), ("G", C.c_int32), ("H0", C.c_int32), ("H1", C.c_int32),
+                ("x", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("Wc", C.c_void_p), ("bc", C.c_void_p), ("p_drop", C.c_float), ("seed", C.c_uint32),
+                ("seed_dev", C.c_void_p), ("sync", C.c_void_p), ("sync_words", C.c_int32), ("trace", C.c_void_p)]
+
+
+class MaxnetGrads(C.Structure):
+    """struct mmf_maxnet_grads (include/mmf_amil.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("dW0", "db0", "dW1", "db1", "dWc", "dbc")]
+
+
 class XReduceIO(C.Structure):
     """struct mmf_xreduce_io (include/mmf_amil.h)."""
     _P3 = C.c_void_p * 3
@@ -94,6 +107,9 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mmf_maxnet_cox_step_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "mmf_maxnet_cox_step": (C.c_int, [C.POINTER(MaxnetDesc), C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_void_p, C.POINTER(MaxnetGrads), C.c_int32, C.c_void_p]),
     "mmf_linear_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "mmf_linear_backward": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

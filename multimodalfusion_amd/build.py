@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmf_amil.so")
 OBJ = os.path.join(HERE, "_build")   # objects and -save-temps output (git- and gpurun-ignored)
-SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_amil_bf16_fwd2.hip", "mmf_amil_bf16_dh2.hip", "mmf_small.hip", "mmf_mlp.hip"]  # missing files are skipped
+SOURCES = ["mmf_api.hip", "mmf_amil_fwd.hip", "mmf_amil_bwd.hip", "mmf_amil_bf16.hip", "mmf_amil_bf16_fwd2.hip", "mmf_amil_bf16_dh2.hip", "mmf_small.hip", "mmf_mlp.hip", "mmf_maxnet.hip"]  # missing files are skipped
 HEADERS = ["mmf_common.h", "mmf_gemm_core.h", "mmf_gemm_split.h", "mmf_gemm_dma.h", "mmf_kernels.h", "mmf_small.h", "mmf_mlp.h", "mmf_bf16.h",
            os.path.join("..", "..", "include", "mmf_amil.h")]
 # Per-file flags.  mmf_amil_bf16_fwd2.hip: no SLP vectorisation, i.e. no packed-fp32 VALU instructions (v_pk_fma_f32 ...).  With

@@ -855,6 +855,39 @@ int mmf_cox_surv(const float* risks, const double* times, const float* c, int32_
   return launch_cox(p, static_cast<hipStream_t>(stream));
 }
 
+size_t mmf_maxnet_cox_step_workspace_bytes(int32_t B) {
+  return maxnet_step_workspace_floats(B < 1 ? 1 : B) * sizeof(float);
+}
+
+int mmf_maxnet_cox_step(const mmf_maxnet_desc* d, const double* times, const float* c, float loss_scale,
+                        void* workspace, size_t workspace_bytes, float* risk, float* loss,
+                        const mmf_maxnet_grads* g, int32_t accumulate, void* stream) {
+  if (!d || !times || !c || !workspace || !risk || !loss || !g) return MMF_ERR_ARG;
+  if (!d->x || !d->W0 || !d->b0 || !d->W1 || !d->b1 || !d->Wc || !d->bc) return MMF_ERR_ARG;
+  if (!g->dW0 || !g->db0 || !g->dW1 || !g->db1 || !g->dWc || !g->dbc) return MMF_ERR_ARG;
+  if (!maxnet_step_ok(d->B, d->G, d->H0, d->H1)) return MMF_ERR_SHAPE;
+  if (!d->sync || d->sync_words < 3) return MMF_ERR_ARG;          // the two grid barriers live in the caller's tick words
+  if (d->p_drop < 0.f || d->p_drop >= 1.f) return MMF_ERR_ARG;
+  if (workspace_bytes < mmf_maxnet_cox_step_workspace_bytes(d->B)) return MMF_ERR_WORKSPACE;
+  MaxnetStepParams p{};
+  p.B = d->B; p.G = d->G;
+  p.x = d->x; p.W0 = d->W0; p.b0 = d->b0; p.W1 = d->W1; p.b1 = d->b1; p.Wc = d->Wc; p.bc = d->bc;
+  p.times = times; p.c = c;
+  p.p = d->p_drop; p.key0 = drop_key(d->seed, 0); p.key1 = drop_key(d->seed, 1); p.seed_dev = d->seed_dev;
+  p.loss_scale = loss_scale;
+  float* w = static_cast<float*>(workspace);
+  const size_t n = (size_t)d->B * 256;
+  p.y0 = w; p.y1 = w + n; p.dp1 = w + 2 * n; p.dp0 = w + 3 * n; p.dr = w + 4 * n;
+  p.stamps = reinterpret_cast<unsigned long long*>(w + 4 * n + (size_t)((d->B + 63) / 64 * 64));      // read by tools/stamps_maxnet.py only
+  p.bar = d->sync;
+  p.risk = risk; p.loss = loss;
+  p.dW0 = g->dW0; p.db0 = g->db0; p.dW1 = g->dW1; p.db1 = g->db1; p.dWc = g->dWc; p.dbc = g->dbc;
+  p.accumulate = accumulate ? 1 : 0;
+  TraceScope ts(d->trace);
+  return launch_maxnet_cox_step(p, static_cast<hipStream_t>(stream));
+}
+
+
 int mmf_adam_l1_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float l1_coeff, const float* l1_mask, int32_t step, void* stream) {
   if (!w || !g || !m || !v || n < 1 || step < 1) return MMF_ERR_ARG;

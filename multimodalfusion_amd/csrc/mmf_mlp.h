@@ -102,4 +102,25 @@ int launch_highway_bwd(HighwayParams p, hipStream_t st);
 int launch_rank_loss(RankParams p, hipStream_t st);
 int launch_hazard_fwd(HazardParams p, hipStream_t st);
 int launch_hazard_bwd(HazardParams p, hipStream_t st);
+// ---- omic head, one training step in one launch (mmf_maxnet.hip) ------------------------------------------------------
+struct MaxnetStepParams {
+  int B, G;
+  const float *x, *W0, *b0, *W1, *b1, *Wc, *bc;
+  const double* times;
+  const float* c;
+  float p;                           // AlphaDropout probability of both blocks (0: eval)
+  uint32_t key0, key1;
+  const uint32_t* seed_dev;
+  float loss_scale;
+  float *y0, *y1, *dp1, *dp0, *dr;   // workspace: [B][256] x 4, [B]
+  unsigned long long* stamps;        // -DMMF_STAMPS builds: 8 words of wall-clock stamps written by workgroup 0, else null
+  unsigned* bar;                     // 3 tick words
+  float *risk, *loss;
+  float *dW0, *db0, *dW1, *db1, *dWc, *dbc;
+  int accumulate;
+};
+size_t maxnet_step_workspace_floats(int B);
+bool maxnet_step_ok(int B, int G, int H0, int H1);
+int launch_maxnet_cox_step(MaxnetStepParams p, hipStream_t st);
+
 }  // namespace mmf

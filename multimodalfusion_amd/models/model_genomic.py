@@ -39,6 +39,39 @@ class MaxNet(MaxNet_base):
     def __init__(self, input_dim: int, model_size_omic: str = "small", bag_loss=None, n_classes: int = 4):
         super().__init__(input_dim, model_size_omic, bag_loss, n_classes)
 
+    def cox_step_ok(self, x):
+        """True when cox_step can take this batch: the `small` net with a Cox head, B <= 256, input_dim <= 256."""
+        return ("nll" not in self.bag_loss and torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and 1 <= x.shape[0] <= 256
+                and x.shape[1] <= 256 and self.fc_omic[0][0].weight.shape[0] == 256 and self.fc_omic[1][0].weight.shape[0] == 256
+                and len(self.fc_omic) == 2 and self.classifier.weight.shape[0] == 1
+                and all(p.requires_grad for p in self.parameters()))
+
+    def cox_step(self, genomic_features, times, c, loss_scale=1.0, grad_out=None, accumulate=None):
+        """Extension of the reference surface (the training-loop mirror uses it): `risk = model(genomic_features=x)[0]`,
+        `loss = CoxSurvLoss()(risks=risk, times=times, c=c)`, `(loss * loss_scale).backward()` as ONE launch
+        (ops.maxnet_cox_step), with the same dropout draw.  `times`: anything CoxSurvLoss accepts; a float64 CUDA tensor
+        saves the per-step host-to-device copy.  Gradients land in the parameters' .grad (accumulated) -- or in `grad_out`
+        (tensors in self.parameters() order; overwritten unless `accumulate`).  Returns (risk [B], loss), detached."""
+        import numpy as np
+        x = genomic_features
+        params = [self.fc_omic[0][0].weight, self.fc_omic[0][0].bias, self.fc_omic[1][0].weight, self.fc_omic[1][0].bias,
+                  self.classifier.weight, self.classifier.bias]
+        if grad_out is not None:
+            grads, accumulate = list(grad_out), bool(accumulate)
+        else:
+            missing = [p for p in params if p.grad is None]
+            accumulate = len(missing) < len(params)
+            for p in missing:
+                p.grad = (torch.zeros_like if accumulate else torch.empty_like)(p)
+            grads = [p.grad for p in params]
+        if not (torch.is_tensor(times) and times.is_cuda and times.dtype == torch.float64):
+            times = torch.as_tensor(np.asarray(times.cpu() if torch.is_tensor(times) else times), dtype=torch.float64).to(x.device)
+        tr = self.training
+        seed = ops.next_dropout_seed() if tr else 0
+        with torch.no_grad():
+            return ops.maxnet_cox_step(x, *params, times, c, grads, loss_scale=loss_scale, accumulate=accumulate,
+                                       p_drop=self.fc_omic[0][2].p if tr else 0.0, seed=seed)
+
     def forward(self, **kwargs):
         x = kwargs["genomic_features"]
         if kwargs.get("return_features"):

@@ -539,6 +539,34 @@ def cox_surv(risks, times, c):
     return CoxSurvFn.apply(risks, times, c)
 
 
+def maxnet_cox_step(x, W0, b0, W1, b1, Wc, bc, times, c, grads, loss_scale=1.0, accumulate=False, p_drop=0.0, seed=0):
+    """MaxNet forward + CoxSurvLoss + backward of one batch in ONE launch (mmf_maxnet_cox_step; models/model_genomic.py:
+    53-72 + utils/loss_utils.py:124-139).  times: float64 CUDA tensor [B]; grads: (dW0, db0, dW1, db1, dWc, dbc) tensors the
+    gradients of loss * loss_scale are written to (or added to, `accumulate`).  Returns (risk [B], loss), detached."""
+    x = _f32c(x)
+    B, G = x.shape
+    dev = x.device
+    if times.dtype != torch.float64 or not times.is_cuda:
+        raise _lib.MmfError("maxnet_cox_step: event times must be a float64 CUDA tensor")
+    sw = sync_words(dev)
+    if sw is None:
+        raise _lib.MmfError("maxnet_cox_step needs tick words (ops.set_sync_override inside a stream capture)")
+    cc = c.reshape(B).to(device=dev, dtype=torch.float32).contiguous()
+    tt = times.reshape(B).contiguous()
+    d = _lib.MaxnetDesc(B=B, G=G, H0=W0.shape[0], H1=W1.shape[0], x=ptr(x), W0=ptr(W0), b0=ptr(b0), W1=ptr(W1), b1=ptr(b1),
+                        Wc=ptr(Wc), bc=ptr(bc), p_drop=float(p_drop), seed=int(seed) & 0xFFFFFFFF, seed_dev=ptr(_seed_word),
+                        sync=ptr(sw), sync_words=SYNC_WORDS, trace=_trace)
+    l = lib()
+    nbytes = l.mmf_maxnet_cox_step_workspace_bytes(B)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    risk = torch.empty((B,), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    g = _lib.MaxnetGrads(*[ptr(t) for t in grads])
+    check(l.mmf_maxnet_cox_step(C.byref(d), ptr(tt), ptr(cc), float(loss_scale), ptr(ws), nbytes, ptr(risk), ptr(loss),
+                                C.byref(g), 1 if accumulate else 0, stream_ptr()), "mmf_maxnet_cox_step")
+    return risk, loss
+
+
 DROP_KIND = {"none": 0, "dropout": 1, "alpha": 2}
 
 

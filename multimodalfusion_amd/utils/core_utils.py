@@ -176,6 +176,22 @@ def _window_of(model, optimizer, world, grad_buffer, inflight, device):
     return w
 
 
+def _fused_cox_ok(model, loss_fn, feats):
+    """One omic batch = one launch (model.cox_step: MaxNet forward + CoxSurvLoss + backward).  Only where that is exactly what
+    `model(**feats)` + the stock loss would compute: MaxNet ITSELF with a Cox head, the stock CoxSurvLoss, no hooks."""
+    from ..models.model_genomic import MaxNet
+    import torch.nn.modules.module as tm
+    x = feats.get("genomic_features")
+    if type(loss_fn) is not CoxSurvLoss or type(model).forward is not MaxNet.forward or not hasattr(model, "cox_step"):
+        return False
+    hooked = lambda m: bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None))
+    if any(hooked(m) for m in model.modules()):
+        return False
+    if tm._global_forward_hooks or tm._global_forward_pre_hooks or tm._global_backward_hooks or getattr(tm, "_global_backward_pre_hooks", None):
+        return False
+    return x is not None and x.dtype == torch.float32 and model.cox_step_ok(x)
+
+
 def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer=None, loss_fn=None, reg_fn=None,
                         lambda_reg=0., gc=16, t_bin=None, dp=False, grad_buffer=None, inflight=1):
     """utils/core_utils.py:173-264: same per-bag order (forward, loss, regulariser added AFTER the /gc division,
@@ -233,7 +249,12 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
                 raise NotImplementedError(type(loss_fn))
 
             fused_step = _fused_step_ok(model, loss_fn, feats)
-            if pipe is not None and fused_step:
+            fused_cox = (not fused_step) and pipe is None and _fused_cox_ok(model, loss_fn, feats)
+            if fused_cox:
+                # the omic batch: MaxNet forward + Cox + backward in one launch; the gradient of loss / G is already in .grad
+                risk, loss = model.cox_step(feats["genomic_features"], event_time, c, loss_scale=1.0 / G)
+                fused_step = True
+            elif pipe is not None and fused_step:
                 _, _, _, _, loss, risk = pipe.run_fused(model, feats["path_features"], label, c, loss_fn.alpha,
                                                         loss_scale=1.0 / G)
             elif pipe is not None:

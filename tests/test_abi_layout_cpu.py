@@ -33,7 +33,8 @@ def _c_layout(tmp_path, structs):
 def test_ctypes_mirrors_match_the_c_header(tmp_path):
     from multimodalfusion_amd import _lib
     mirrors = {"mmf_amil_desc": _lib.AmilDesc, "mmf_amil_grads": _lib.AmilGrads, "mmf_surv_head": _lib.SurvHead,
-               "mmf_nll_target": _lib.NllTarget, "mmf_xreduce_io": _lib.XReduceIO}
+               "mmf_nll_target": _lib.NllTarget, "mmf_xreduce_io": _lib.XReduceIO, "mmf_maxnet_desc": _lib.MaxnetDesc,
+               "mmf_maxnet_grads": _lib.MaxnetGrads}
     structs = {c: [n for n, _ in m._fields_] for c, m in mirrors.items()}
     got = _c_layout(tmp_path, structs)
     import ctypes as C

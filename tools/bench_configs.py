@@ -30,7 +30,18 @@ cox = CoxSurvLoss()
 def omic_step():
     for p in omic.parameters(): p.grad = None
     risk = omic(genomic_features=ox)[0]; cox(risks=risk, times=ot, c=oc).backward()
-print(f"max_net B=128 G=36 Cox fwd+bwd: {timeit(omic_step):.3f} ms/step")
+print(f"max_net B=128 G=36 Cox fwd+bwd, composable path: {timeit(omic_step):.3f} ms/step")
+ot_dev = ot.to(dev) if torch.is_tensor(ot) else torch.as_tensor(ot, dtype=torch.float64).to(dev)
+def omic_one_launch():
+    for p in omic.parameters(): p.grad = None
+    omic.cox_step(ox, ot_dev, oc)
+print(f"max_net B=128 G=36 Cox fwd+bwd, one launch (MaxNet.cox_step): {timeit(omic_one_launch):.3f} ms/step")
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+grads = [torch.zeros_like(p) for p in omic.parameters()]
+torch.cuda.synchronize(); ev[0].record()
+for _ in range(200): omic.cox_step(ox, ot_dev, oc, grad_out=grads, accumulate=False)
+ev[1].record(); torch.cuda.synchronize()
+print(f"   the same, 200 back-to-back steps by HIP events: {ev[0].elapsed_time(ev[1]) / 200:.4f} ms/step")
 # multimodal
 for fusion in ("concat", "tensor"):
     mm = MM_MIL_Attention_fc_surv(input_dim=80, fusion=fusion, n_classes=4).to(dev).train()
