@@ -31,7 +31,6 @@ constexpr float MX_SELU_SCALE = 1.0507009873554805f;
 constexpr int MX_H = 256;            // both hidden widths of the `small` omic net (model_genomic.py:17)
 constexpr int MX_NW = 32;            // workgroups
 constexpr int MX_NS = MX_H / MX_NW;  // output features per workgroup in phase 4
-constexpr int MX_WP = 65;            // LDS pitch of a staged weight chunk [256][64 + 1]
 
 
 __device__ inline float mx_selu(float v) { return MX_SELU_SCALE * (v > 0.f ? v : MX_SELU_ALPHA * (expf(v) - 1.0f)); }
@@ -62,28 +61,52 @@ __device__ inline void mx_grid_barrier(unsigned* cnt) {
 // acc[r] = sum_k xs[k][r] W[n = tid][k], k < K: W (row-major [256][ldw]) is staged through LDS in chunks of 64 k so that the
 // global reads are coalesced along k and thread n's reads walk its own padded row; the next chunk travels in registers
 // while this one is multiplied.  xs: [K][R] in LDS (R batch values of one k contiguous: one broadcast read per k).
-template <int R>
+// VEC (ldw % 4 == 0, K % 64 == 0, 16-byte aligned W): 16-byte global loads, LDS writes and LDS reads; the row pitch of 68
+// floats keeps both the b128 writes (a quarter wave writes 16 slots of one row) and the b128 reads (a quarter wave reads the
+// same four k of 16 consecutive rows: 16 x 4 distinct banks) conflict-free.  `pre` runs once, right behind the first chunk's
+// load requests: work that does not depend on W hides their latency.
+constexpr int MX_WP = 68;
+template <int R, bool VEC, class Pre>
 __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* __restrict__ W, int ldw, int K, float* wl,
-                                    float (&acc)[R]) {
+                                    float (&acc)[R], Pre&& pre) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  float stage[64];
-  auto fetch = [&](int k0) {         // thread t: elements e = t + 256 i of the [256][64] chunk, i.e. row e / 64, column e % 64
+  float4 stage[16];
+  auto fetch = [&](int k0) {
+    if constexpr (VEC) {             // thread t: float4 e = t + 256 i of the [256][16 float4] chunk: row e / 16, float4 e % 16
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int e = tid + 256 * i, n = e >> 6, kk = e & 63;
-      stage[i] = (k0 + kk < K) ? W[(size_t)n * ldw + k0 + kk] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        stage[i] = ld4(W + (size_t)(e >> 4) * ldw + k0 + 4 * (e & 15));
+      }
+    } else {                         // any ldw / K: scalars, element e = t + 256 i: row e / 64, column e % 64
+      float* sf = reinterpret_cast<float*>(stage);
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int e = tid + 256 * i, n = e >> 6, kk = e & 63;
+        sf[i] = (k0 + kk < K) ? W[(size_t)n * ldw + k0 + kk] : 0.f;
+      }
     }
   };
   auto put = [&]() {
+    if constexpr (VEC) {
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int e = tid + 256 * i;
-      wl[(e >> 6) * MX_WP + (e & 63)] = stage[i];
+      for (int i = 0; i < 16; ++i) {
+        const int e = tid + 256 * i;
+        st4(wl + (e >> 4) * MX_WP + 4 * (e & 15), stage[i]);
+      }
+    } else {
+      const float* sf = reinterpret_cast<const float*>(stage);
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const int e = tid + 256 * i;
+        wl[(e >> 6) * MX_WP + (e & 63)] = sf[i];
+      }
     }
   };
   fetch(0);
+  pre();
   for (int k0 = 0; k0 < K; k0 += 64) {
     __syncthreads();                 // the previous chunk has been read by everybody
     put();
@@ -94,9 +117,11 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
     if (kn == 64) {                  // a full chunk: 16 k at a time, their LDS reads issued together
 #pragma unroll 1
       for (int kq = 0; kq < 64; kq += 16) {
-        float w[16];
+        float4 w4[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = wr[kq + u];
+        for (int u = 0; u < 4; ++u) w4[u] = ld4(wr + kq + 4 * u);
+        const float w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                             w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const float* xv = xs + (size_t)(k0 + kq + u) * R;
@@ -105,6 +130,7 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
         }
       }
     } else {
+#pragma unroll 4
       for (int kk = 0; kk < kn; ++kk) {
         const float w = wr[kk];
         const float* xv = xs + (size_t)(k0 + kk) * R;
@@ -112,6 +138,21 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
         for (int r = 0; r < R; ++r) acc[r] += xv[r] * w;
       }
     }
+  }
+}
+
+// dst[e] = src(e) for e < n, every thread's loads of a batch of 8 issued before its first LDS store (a plain loop is one
+// memory round trip per element: the compiler keeps a load in front of the store that might alias it)
+template <class Src>
+__device__ inline void mx_stage(float* dst, int n, Src&& src) {
+  const int tid = threadIdx.x;
+  for (int e0 = tid; e0 < n; e0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = e0 + 256 * u < n ? src(e0 + 256 * u) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 256 * u < n) dst[e0 + 256 * u] = v[u];
   }
 }
 
@@ -126,7 +167,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   extern __shared__ __align__(16) float sm[];
   MX_STAMP(0);
   float* xs = sm;                               // [256][R] layer input of this workgroup's rows
-  float* wl = xs + 256 * R;                     // [256][65] staged weights; phases 2-4: scratch
+  float* wl = xs + 256 * R;                     // [256][68] staged weights; phases 2-4: scratch
   float* red = wl + 256 * MX_WP;                // [4][R] + misc
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = p.B, G = p.G;
@@ -136,12 +177,13 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   const uint32_t key0 = p.key0 + sdev, key1 = p.key1 + sdev;
 
   // ---------------- phase 1: this workgroup's rows through the net ----------------------------------------------------
-  for (int e = tid; e < G * R; e += 256) {
-    const int k = e / R, r = e % R;
-    xs[e] = (r0 + r < B) ? p.x[(size_t)(r0 + r) * G + k] : 0.f;
-  }
   float acc[R], y0d[R], y1d[R];
-  mx_rows_gemm<R>(xs, p.W0, G, G, wl, acc);
+  mx_rows_gemm<R, false>(xs, p.W0, G, G, wl, acc, [&]() {
+    for (int e = tid; e < G * R; e += 256) {    // the rows' inputs, behind W0's load requests
+      const int k = e / R, r = e % R;
+      xs[e] = (r0 + r < B) ? p.x[(size_t)(r0 + r) * G + k] : 0.f;
+    }
+  });
   MX_STAMP(1);
   {
     const float b = p.b0[tid];
@@ -153,21 +195,20 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
       if (r0 + r < B) p.y0[(size_t)(r0 + r) * MX_H + tid] = y0d[r];
     }
   }
-  __syncthreads();                              // every thread is done with xs as layer 0's input
+  const float b1v = p.b1[tid], wcv = p.Wc[tid], bcv = p.bc[0];
+  mx_rows_gemm<R, true>(xs, p.W1, MX_H, MX_H, wl, acc, [&]() {
+    __syncthreads();                            // every thread is done with xs as layer 0's input
 #pragma unroll
-  for (int r = 0; r < R; ++r) xs[tid * R + r] = y0d[r];
-  mx_rows_gemm<R>(xs, p.W1, MX_H, MX_H, wl, acc);
+    for (int r = 0; r < R; ++r) xs[tid * R + r] = y0d[r];
+  });
   float part[R];
-  {
-    const float b = p.b1[tid], wc = p.Wc[tid];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float y = mx_selu(acc[r] + b);
-      const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
-      y1d[r] = dr.on ? dr.a * (keep(key1, idx, dr.thr) ? y : dr.alpha_p) + dr.b : y;
-      if (r0 + r < B) p.y1[(size_t)(r0 + r) * MX_H + tid] = y1d[r];
-      part[r] = wave_sum(y1d[r] * wc);
-    }
+  for (int r = 0; r < R; ++r) {
+    const float y = mx_selu(acc[r] + b1v);
+    const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
+    y1d[r] = dr.on ? dr.a * (keep(key1, idx, dr.thr) ? y : dr.alpha_p) + dr.b : y;
+    if (r0 + r < B) p.y1[(size_t)(r0 + r) * MX_H + tid] = y1d[r];
+    part[r] = wave_sum(y1d[r] * wcv);
   }
   __syncthreads();
   if (lane == 0) {
@@ -175,54 +216,75 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     for (int r = 0; r < R; ++r) red[wave * R + r] = part[r];
   }
   __syncthreads();
-  if (tid < R && r0 + tid < B) p.risk[r0 + tid] = red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + p.bc[0];
+  if (tid < R && r0 + tid < B) p.risk[r0 + tid] = red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + bcv;
   MX_STAMP(2);
   mx_grid_barrier(p.bar);
   MX_STAMP(3);
 
   // ---------------- phase 2: Cox over the whole batch, gradient of this workgroup's rows ---------------------------------
-  float* et = wl;                               // [B] e^theta
-  float* wq = wl + 256;                         // [B] (1 - c_i) / D_i
-  float* lp = wl + 512;                         // [256] loss terms (workgroup 0)
-  double* tl = reinterpret_cast<double*>(wl + 768);     // [B] event times
-  for (int i = tid; i < B; i += 256) { et[i] = expf(p.risk[i]); tl[i] = p.times[i]; }
+  float* th = wl;                               // [256] theta
+  float* et = wl + 256;                         // [256] e^theta
+  float* uc = wl + 512;                         // [256] 1 - c
+  float* wq = wl + 768;                         // [256] (1 - c_i) / D_i
+  float* lp = wl + 1024;                        // [4] loss terms per wave
+  double* tl = reinterpret_cast<double*>(wl + 1280);    // [256] event times
+  if (tid < B) {
+    const float t = p.risk[tid];
+    th[tid] = t; et[tid] = expf(t); uc[tid] = 1.f - p.c[tid]; tl[tid] = p.times[tid];
+  }
   __syncthreads();
   float lterm = 0.f;
-  for (int i = tid; i < B; i += 256) {
-    const double ti = tl[i];
-    float Di = 0.f;
-    for (int j = 0; j < B; ++j) Di += (tl[j] >= ti) ? et[j] : 0.f;
-    const float unc = 1.f - p.c[i];
-    lterm += (p.risk[i] - logf(Di)) * unc;
-    wq[i] = unc / Di;
+  if (tid < B) {                                // B <= 256: one risk set per thread
+    const double ti = tl[tid];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    int j = 0;
+    for (; j + 3 < B; j += 4) {
+      d0 += (tl[j] >= ti) ? et[j] : 0.f; d1 += (tl[j + 1] >= ti) ? et[j + 1] : 0.f;
+      d2 += (tl[j + 2] >= ti) ? et[j + 2] : 0.f; d3 += (tl[j + 3] >= ti) ? et[j + 3] : 0.f;
+    }
+    for (; j < B; ++j) d0 += (tl[j] >= ti) ? et[j] : 0.f;
+    const float Di = (d0 + d1) + (d2 + d3);
+    lterm = (th[tid] - logf(Di)) * uc[tid];
+    wq[tid] = uc[tid] / Di;
   }
-  lp[tid] = lterm;
+  lterm = wave_sum(lterm);
+  if (lane == 0) lp[wave] = lterm;
   __syncthreads();
   const float invB = 1.0f / (float)B;
-  if (tid < R) {
-    float g = 0.f;
-    const int k = r0 + tid;
+  {
+    // row r of this workgroup: sum_i [t_k >= t_i] w_i over the batch, R rows x (256 / R) threads each
+    constexpr int TPR = 256 / R;
+    const int r = tid / TPR, q = tid % TPR, k = r0 + r;
+    float a = 0.f;
     if (k < B) {
       const double tk = tl[k];
-      float a = 0.f;
-      for (int i = 0; i < B; ++i) a += (tk >= tl[i]) ? wq[i] : 0.f;
-      g = -invB * ((1.f - p.c[k]) - et[k] * a) * p.loss_scale;
-      p.dr[k] = g;
+      for (int i = q; i < B; i += TPR) a += (tk >= tl[i]) ? wq[i] : 0.f;
     }
-    red[tid] = g;
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);       // TPR <= 64: within one wave
+    if (q == 0) {
+      float g = 0.f;
+      if (k < B) {
+        g = -invB * (uc[k] - et[k] * a) * p.loss_scale;
+        p.dr[k] = g;
+      }
+      red[r] = g;
+    }
   }
-  if (blockIdx.x == 0 && tid == 0) {
-    float s = 0.f;
-    for (int i = 0; i < 256; ++i) s += lp[i];
-    p.loss[0] = -s * invB;
-  }
+  if (blockIdx.x == 0 && tid == 0) p.loss[0] = -((lp[0] + lp[1]) + (lp[2] + lp[3])) * invB;
   __syncthreads();
 
   MX_STAMP(4);
   // ---------------- phase 3: d pre-activations of this workgroup's rows --------------------------------------------------
   float* dps = xs;                              // [256][R] dpre1 of these rows (layer 1's outputs n)
+  constexpr int SG3 = 32;
+  float w3[2][SG3];                             // dy0's first two stages of W1 rows, requested before anything else
+#pragma unroll
+  for (int u = 0; u < SG3; ++u) w3[0][u] = p.W1[(size_t)u * MX_H + tid];
+#pragma unroll
+  for (int u = 0; u < SG3; ++u) w3[1][u] = p.W1[(size_t)(SG3 + u) * MX_H + tid];
   {
-    const float wc = p.Wc[tid];
+    float wpart = 0.f;                          // this workgroup's share of dWc[k = tid] = sum_b dr[b] y1[b][k]
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
@@ -232,10 +294,11 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
         dydy = kp ? dr.a : 0.f;
         y = kp ? (y1d[r] - dr.b) / dr.a : 0.f;
       }
-      const float d = red[r] * wc * dydy * mx_selu_grad_from_y(y);
+      const float d = red[r] * wcv * dydy * mx_selu_grad_from_y(y);
       dps[tid * R + r] = d;
-      if (r0 + r < B) p.dp1[(size_t)(r0 + r) * MX_H + tid] = d;
+      if (r0 + r < B) { p.dp1[(size_t)(r0 + r) * MX_H + tid] = d; wpart += red[r] * y1d[r]; }
     }
+    p.dwc_part[(size_t)blockIdx.x * MX_H + tid] = wpart;
   }
   __syncthreads();
   {
@@ -244,23 +307,24 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     for (int r = 0; r < R; ++r) a[r] = 0.f;
     // dy0[r][k = tid] = sum_n dpre1[r][n] W1[n][k]: W1 is read as it lies (row n, coalesced along k), 16 rows per stage and the
     // next stage's 16 loads in flight while this one multiplies (the loop is a chain of memory round trips otherwise)
-    float w[2][16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) w[0][u] = p.W1[(size_t)u * MX_H + tid];
+    // (64 rows per stage, two stages requested before the first is used: with 16-row stages every stage waited out a full
+    // memory round trip, 16 of them)
+    constexpr int SG = SG3;
+    float (&w)[2][SG3] = w3;
 #pragma unroll 1
-    for (int n0 = 0; n0 < MX_H; n0 += 32) {
+    for (int nb0 = 0; nb0 < MX_H; nb0 += 2 * SG) {       // not unrolled: the compiler would request all 256 rows at once
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int nb = n0 + 16 * h, nn = nb + 16;
-        if (nn < MX_H) {
+        const int nb = nb0 + h * SG;
 #pragma unroll
-          for (int u = 0; u < 16; ++u) w[h ^ 1][u] = p.W1[(size_t)(nn + u) * MX_H + tid];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < SG; ++u) {
           const float* dv = dps + (nb + u) * R;
 #pragma unroll
           for (int r = 0; r < R; ++r) a[r] += dv[r] * w[h][u];
+        }
+        if (nb + 2 * SG < MX_H) {
+#pragma unroll
+          for (int u = 0; u < SG; ++u) w[h][u] = p.W1[(size_t)(nb + 2 * SG + u) * MX_H + tid];
         }
       }
     }
@@ -284,37 +348,50 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   const int n0 = blockIdx.x * MX_NS;
   float* d1s = wl;                              // [B][8] dpre1[:, n0 .. n0 + 7]
   float* d0s = wl + 8 * 256;                    // [B][8] dpre0[:, n0 .. n0 + 7]   (B <= 256)
-  for (int e = tid; e < B * MX_NS; e += 256) {
-    const int b = e / MX_NS, i = e % MX_NS;
-    d1s[e] = p.dp1[(size_t)b * MX_H + n0 + i];
-    d0s[e] = p.dp0[(size_t)b * MX_H + n0 + i];
+  float* xl = wl + 16 * 256;                    // x rows in blocks of XB rows (dW0)
+  const int XB = (256 * MX_WP - 16 * 256) / G;  // rows of x that fit behind d1s / d0s
+  // everything this phase reads from memory is requested up front, where the addresses do not depend on anything computed here
+  float cpart[8];
+  if (blockIdx.x == 0) {                        // classifier: dWc[k] = sum over the workgroups' shares, in workgroup order
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cpart[u] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MX_NW; ++j) cpart[j & 7] += p.dwc_part[(size_t)j * MX_H + tid];
   }
+  // (the first two stages of dW1's y0 rows are requested here too: one round trip for all of it)
+  constexpr int SG4 = 32;
+  float yv[2][SG4];
+  auto ld = [&](int b0, float (&v)[SG4]) {
+#pragma unroll
+    for (int u = 0; u < SG4; ++u) v[u] = b0 + u < B ? p.y0[(size_t)(b0 + u) * MX_H + tid] : 0.f;
+  };
+  ld(0, yv[0]);
+  ld(SG4, yv[1]);
+  mx_stage(d1s, B * MX_NS, [&](int e) { return p.dp1[(size_t)(e / MX_NS) * MX_H + n0 + e % MX_NS]; });
+  mx_stage(d0s, B * MX_NS, [&](int e) { return p.dp0[(size_t)(e / MX_NS) * MX_H + n0 + e % MX_NS]; });
+  const int xb0 = B < XB ? B : XB;
+  mx_stage(xl, xb0 * G, [&](int e) { return p.x[e]; });
   __syncthreads();
+  MX_STAMP(8);
   {
     float a[MX_NS];
 #pragma unroll
     for (int i = 0; i < MX_NS; ++i) a[i] = 0.f;
-    // dW1[n0 + i][k = tid] = sum_b dpre1[b][n0 + i] y0[b][k]: 16 batch rows per stage, the next stage in flight; rows beyond
-    // the batch multiply zeros of d1s' padding... they are simply not loaded (yv = 0)
-    float yv[2][16];
-    auto ld = [&](int b0, float (&v)[16]) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = b0 + u < B ? p.y0[(size_t)(b0 + u) * MX_H + tid] : 0.f;
-    };
-    ld(0, yv[0]);
+    // dW1[n0 + i][k = tid] = sum_b dpre1[b][n0 + i] y0[b][k]: 16 batch rows per stage, the next stage in flight
+    constexpr int SG = SG4;
 #pragma unroll 1
-    for (int b0 = 0; b0 < B; b0 += 32) {
+    for (int b0 = 0; b0 < B; b0 += 2 * SG) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int bb = b0 + 16 * h;
-        if (bb >= B) break;
-        if (bb + 16 < B) ld(bb + 16, yv[h ^ 1]);
+        const int bb = b0 + SG * h;
+        if (bb < B) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          if (bb + u >= B) break;
-          const float* dv = d1s + (bb + u) * MX_NS;
+          for (int u = 0; u < SG; ++u) {
+            const float* dv = d1s + (bb + u < B ? bb + u : 0) * MX_NS;      // rows beyond the batch: yv = 0
 #pragma unroll
-          for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * yv[h][u];
+            for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * yv[h][u];
+          }
+          if (bb + 2 * SG < B) ld(bb + 2 * SG, yv[h]);
         }
       }
     }
@@ -324,41 +401,59 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
       *o = p.accumulate ? *o + a[i] : a[i];
     }
   }
-  if (tid < G) {                                 // dW0[n0 + i][g = tid] = sum_b dpre0[b][n0 + i] x[b][g]   (G <= 256)
+  MX_STAMP(9);
+  {                                              // dW0[n0 + i][g = tid] = sum_b dpre0[b][n0 + i] x[b][g]   (G <= 256)
     float a[MX_NS];
 #pragma unroll
     for (int i = 0; i < MX_NS; ++i) a[i] = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) {
-      const float xv = p.x[(size_t)b * G + tid];
-      const float* dv = d0s + b * MX_NS;
+    for (int bs = 0; bs < B; bs += XB) {         // x through LDS, XB rows at a time (all of it at B = 128, G = 36)
+      const int nb = B - bs < XB ? B - bs : XB;
+      if (bs > 0) {
+        __syncthreads();
+        mx_stage(xl, nb * G, [&](int e) { return p.x[(size_t)bs * G + e]; });
+        __syncthreads();
+      }
+      if (tid < G) {
+#pragma unroll 4
+        for (int b = 0; b < nb; ++b) {
+          const float xv = xl[b * G + tid];
+          const float* dv = d0s + (bs + b) * MX_NS;
 #pragma unroll
-      for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * xv;
+          for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * xv;
+        }
+      }
     }
+    if (tid < G) {
 #pragma unroll
-    for (int i = 0; i < MX_NS; ++i) {
-      float* o = p.dW0 + (size_t)(n0 + i) * G + tid;
-      *o = p.accumulate ? *o + a[i] : a[i];
+      for (int i = 0; i < MX_NS; ++i) {
+        float* o = p.dW0 + (size_t)(n0 + i) * G + tid;
+        *o = p.accumulate ? *o + a[i] : a[i];
+      }
     }
   }
+  MX_STAMP(10);
   if (tid < 2 * MX_NS) {                         // db1 / db0 of the slice
     const int i = tid % MX_NS;
     const float* src = tid < MX_NS ? d1s : d0s;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += src[b * MX_NS + i];
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0;
+    for (; b + 1 < B; b += 2) { s0 += src[b * MX_NS + i]; s1 += src[(b + 1) * MX_NS + i]; }
+    if (b < B) s0 += src[b * MX_NS + i];
     float* o = (tid < MX_NS ? p.db1 : p.db0) + n0 + i;
-    *o = p.accumulate ? *o + s : s;
+    *o = p.accumulate ? *o + (s0 + s1) : (s0 + s1);
   }
-  if (blockIdx.x == 0) {                         // classifier: dWc[k] = sum_b dr[b] y1[b][k], dbc = sum_b dr[b]
-    float s = 0.f, sb = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) {
-      const float g = p.dr[b];
-      s += g * p.y1[(size_t)b * MX_H + tid];
-      sb += g;
-    }
+  MX_STAMP(11);
+  if (blockIdx.x == 0) {
+    const float s = ((cpart[0] + cpart[1]) + (cpart[2] + cpart[3])) + ((cpart[4] + cpart[5]) + (cpart[6] + cpart[7]));
     p.dWc[tid] = p.accumulate ? p.dWc[tid] + s : s;
-    if (tid == 0) p.dbc[0] = p.accumulate ? p.dbc[0] + sb : sb;
+    float sb = tid < B ? p.dr[tid] : 0.f;       // dbc = sum_b dr[b]
+    sb = wave_sum(sb);
+    if (lane == 0) red[8 + wave] = sb;
+    __syncthreads();
+    if (tid == 0) {
+      const float t = (red[8] + red[9]) + (red[10] + red[11]);
+      p.dbc[0] = p.accumulate ? p.dbc[0] + t : t;
+    }
   }
   MX_STAMP(7);
   // the tick words go back to zero: the last workgroup to get here knows that everybody has passed both barriers
@@ -373,7 +468,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
 }
 
-size_t maxnet_step_workspace_floats(int B) { return (size_t)4 * B * MX_H + (size_t)((B + 63) / 64 * 64) + 16; }
+size_t maxnet_step_workspace_floats(int B) { return (size_t)4 * B * MX_H + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW * MX_H; }
 
 bool maxnet_step_ok(int B, int G, int H0, int H1) { return B >= 1 && B <= 256 && G >= 1 && G <= 256 && H0 == MX_H && H1 == MX_H; }
 

@@ -113,6 +113,7 @@ struct MaxnetStepParams {
   const uint32_t* seed_dev;
   float loss_scale;
   float *y0, *y1, *dp1, *dp0, *dr;   // workspace: [B][256] x 4, [B]
+  float* dwc_part;                   // workspace: [32 workgroups][256] shares of dWc
   unsigned long long* stamps;        // -DMMF_STAMPS builds: 8 words of wall-clock stamps written by workgroup 0, else null
   unsigned* bar;                     // 3 tick words
   float *risk, *loss;

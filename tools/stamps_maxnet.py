@@ -24,6 +24,8 @@ for it in range(5):
     rc = l.mmf_maxnet_cox_step(C.byref(d), t.data_ptr(), c.data_ptr(), 1.0, ws.data_ptr(), nbytes, risk.data_ptr(), loss.data_ptr(), C.byref(g), 0, None)
     assert rc == 0
     torch.cuda.synchronize()
-    st = ws[-64:].view(torch.int64).cpu().numpy()
+    off = (4 * 128 * 256 + 128) * 4
+    st = ws[off:off + 128].view(torch.int64).cpu().numpy()
     names = ["L0 gemm", "L1 + classifier", "barrier 1", "Cox", "phase 3", "barrier 2", "phase 4"]
-    print("  ".join(f"{n} {int(st[i + 1] - st[i])}" for i, n in enumerate(names)), " total cycles", int(st[7] - st[0]))
+    print("  ".join(f"{n} {int(st[i + 1] - st[i])}" for i, n in enumerate(names)), " total cycles", int(st[7] - st[0]),
+          "| phase 4: staging", int(st[8] - st[6]), "dW1", int(st[9] - st[8]), "dW0", int(st[10] - st[9]), "db", int(st[11] - st[10]), "dWc/dbc", int(st[7] - st[11]))
