@@ -208,7 +208,12 @@ __global__ __launch_bounds__(256, 2) void amil_fwd_fused2_bf16_kernel(FusedFwdPa
     // epilogue only applies them.  Element e = ((fb 4 + ib) 4 + g) 4 + j of this lane is hashed in chunk e / 8.
     {
       auto iter = [&](int kt, f32x4v (&wcur)[8], f32x4v (&wnext)[8]) {
+#ifdef MMF_F2_COND_LOAD     /* diagnostic build (tools/diag_build.py f2cond*): the weight refill as a CONDITIONAL definition of the
+                               asm-loaded registers, as an intermediate round-3 version had it -- what the branch-free loop replaced */
+        if (kt + 1 < nk) load_w(kt + 1, wnext);
+#else
         if (!(dbg & 2)) load_w(kt + 1, wnext);
+#endif
         if (!(dbg & 1)) lx.issue(kt + 2, stage(kt + 2), kt + 2 < nk ? 0u : 0x80000000u);
         uint32_t bits = 0;
         const uint32_t sC = __builtin_amdgcn_readfirstlane((uint32_t)(((kt >> 1) & 3) * 8192 + (kt >> 3) * 32 + (kt & 1) * 16) * 0x9E3779B1u);

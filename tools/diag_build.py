@@ -25,7 +25,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from multimodalfusion_amd import build as B   # noqa: E402
 
-VARIANTS = {"tune": ["-DMMF_TUNE"],      # the product kernels + the MMF_* environment overrides of the launch plans (tools/README.md)
+# round 4: the fused bf16 forward built WITH the SLP vectoriser (the shipped library builds it without: build.py FILE_FLAGS),
+# alone and with one suspect removed at a time -- tools/f2_slp_hazard.sh runs the determinism stress on each
+#   f2slp      SLP on: 316 v_pk_*_f32 in the kernel (the round-3 corruption)
+#   f2slp_wz   + s_waitcnt 0 behind every memory instruction (is it a counter the compiler mis-tracks?)
+#   f2slp_nopk + the packed-fp32 instructions switched off in the backend (SLP's reordering without v_pk_*)
+#   f2cond / f2cond_slp   the weight refill of the main loop as a conditional definition of the asm-loaded registers (what
+#              the branch-free loop of the same round-3 commit replaced), without / with SLP
+NO_FILE_FLAGS = {"f2slp", "f2slp_wz", "f2slp_nopk", "f2cond_slp"}
+VARIANTS = {"f2cond": ["-DMMF_F2_COND_LOAD"], "f2cond_slp": ["-DMMF_F2_COND_LOAD"],
+            "f2slp": [], "f2slp_wz": ["-mllvm", "-amdgpu-waitcnt-forcezero=1"],
+            "f2slp_nopk": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+            "tune": ["-DMMF_TUNE"],      # the product kernels + the MMF_* environment overrides of the launch plans (tools/README.md)
             "noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
             "f2noact": ["-DMMF_F2_GATE_NOACT"], "f2nown": ["-DMMF_F2_GATE_NOWN"], "f2nomm": ["-DMMF_F2_GATE_NOMM"],
@@ -62,7 +73,8 @@ def main():
         for s in B.SOURCES:
             obj = os.path.join(objdir, s.replace(".hip", ".o"))
             objs.append(obj)
-            jobs.append([B.HIPCC] + B.FLAGS + B.FILE_FLAGS.get(s, []) + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj])
+            ff = [] if name in NO_FILE_FLAGS else B.FILE_FLAGS.get(s, [])
+            jobs.append([B.HIPCC] + B.FLAGS + ff + flags + ["-c", os.path.join(B.CSRC, s), "-o", obj])
         with ThreadPoolExecutor(max_workers=4) as ex:
             for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs):
                 if r.returncode != 0:

@@ -37,6 +37,16 @@ def step():
     loss_of(model(**kw)).backward()
 
 
+if what == "omic":          # what the training-loop mirror runs for this model: the one-launch step (MaxNet.cox_step)
+    ot_dev = ot.to(dev)
+    x_omic = kw["genomic_features"]
+
+    def step():
+        for p in params:
+            p.grad = None
+        model.cox_step(x_omic, ot_dev, oc)
+
+
 for _ in range(10):
     step()
 torch.cuda.synchronize()
