@@ -46,6 +46,29 @@ class MaxNet(MaxNet_base):
                 and len(self.fc_omic) == 2 and self.classifier.weight.shape[0] == 1
                 and all(p.requires_grad for p in self.parameters()))
 
+    def _times_to_device(self, t, device):
+        """Event times as the loader delivers them (a host array) -> float64 on the device through a small ring of PINNED
+        staging buffers and an asynchronous copy: no pageable copy, no host synchronisation per step (the reference's loop
+        does `torch.tensor(event_time)` + a blocking .to(device) every step, utils/core_utils.py:204).  A ring slot is
+        reused only after the copy that last read it has completed (an event per slot, normally long done)."""
+        n = int(t.size)
+        ring = self.__dict__.get("_mmf_times_ring")
+        if ring is None or ring["cap"] < n or ring["device"] != device:
+            cap = max(256, n)
+            ring = dict(cap=cap, device=device, i=0, bufs=[torch.empty(cap, dtype=torch.float64).pin_memory() for _ in range(4)],
+                        evs=[None] * 4)
+            self.__dict__["_mmf_times_ring"] = ring          # not a parameter / buffer: stays out of state_dict
+        k = ring["i"] = (ring["i"] + 1) % 4
+        if ring["evs"][k] is not None:
+            ring["evs"][k].synchronize()
+        buf = ring["bufs"][k][:n]
+        buf.numpy()[:] = t.reshape(-1)
+        out = buf.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        ring["evs"][k] = ev
+        return out
+
     def cox_step(self, genomic_features, times, c, loss_scale=1.0, grad_out=None, accumulate=None):
         """Extension of the reference surface (the training-loop mirror uses it): `risk = model(genomic_features=x)[0]`,
         `loss = CoxSurvLoss()(risks=risk, times=times, c=c)`, `(loss * loss_scale).backward()` as ONE launch
@@ -65,7 +88,7 @@ class MaxNet(MaxNet_base):
                 p.grad = (torch.zeros_like if accumulate else torch.empty_like)(p)
             grads = [p.grad for p in params]
         if not (torch.is_tensor(times) and times.is_cuda and times.dtype == torch.float64):
-            times = torch.as_tensor(np.asarray(times.cpu() if torch.is_tensor(times) else times), dtype=torch.float64).to(x.device)
+            times = self._times_to_device(np.asarray(times.cpu() if torch.is_tensor(times) else times, dtype=np.float64), x.device)
         tr = self.training
         seed = ops.next_dropout_seed() if tr else 0
         with torch.no_grad():
