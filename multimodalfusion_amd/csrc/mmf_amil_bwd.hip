@@ -1387,7 +1387,7 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
     // the half-block tile's epilogue exists for the relu-bits path only (every stack backward; not the standalone scorer)
     switch (pick_wide_rows(p.N, p.H / 256, p.allow_half && p.fused_prep && p.relu_bits, p.concurrent != 0, DH_MAX_ROWS)) {
 #define MMF_WIDE_CASE(R) case R: return launch_bwd_dh_wide<R>(p, st);
-      MMF_WIDE_CASE(48) MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
+      MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
       MMF_WIDE_CASE(144) MMF_WIDE_CASE(160) MMF_WIDE_CASE(176) MMF_WIDE_CASE(192) MMF_WIDE_CASE(208)
 #undef MMF_WIDE_CASE
       default: return launch_bwd_dh_wide<224>(p, st);

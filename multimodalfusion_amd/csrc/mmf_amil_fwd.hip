@@ -895,7 +895,7 @@ int launch_linear(LinearParams p, hipStream_t st) {
   if (use_wide_tiles(p.M, p.N, can_split)) {
     switch (pick_wide_rows(p.M, p.N / 256, p.allow_half != 0, p.concurrent != 0, 240)) {
 #define MMF_WIDE_CASE(R) case R: return launch_linear_wide<R>(p, st);
-      MMF_WIDE_CASE(48) MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
+      MMF_WIDE_CASE(64) MMF_WIDE_CASE(80) MMF_WIDE_CASE(96) MMF_WIDE_CASE(112) MMF_WIDE_CASE(128)
       MMF_WIDE_CASE(144) MMF_WIDE_CASE(160) MMF_WIDE_CASE(176) MMF_WIDE_CASE(192) MMF_WIDE_CASE(208) MMF_WIDE_CASE(240)
 #undef MMF_WIDE_CASE
       default: return launch_linear_wide<224>(p, st);
