@@ -1400,6 +1400,20 @@ int launch_bwd_dh(BwdDhParams p, hipStream_t st) {
     p.mt_count = (int)((p.N + 127) / 128); p.nt_count = ntn;
     return launch_tiled<T>("bwd_dh_kernel", bwd_dh_kernel<T, false>, p, grid_for_tiles(p.mt_count, p.nt_count), st);
   }
+  {
+    // 64 x 128 tiles (two column tiles of a row tile instead of four: the dP operand and K-prep are built twice, not four
+    // times, and a workgroup's chunk holds 32 MFMAs per wave instead of 16) where they fill the 512 slots once: measured
+    // (round 4, same call, K-dh us 64 x 64 -> 64 x 128): 14,000 rows 56.7 -> 50.0, 16,000 57.1 -> 50.1; 12,288 43.2 -> 49.1,
+    // 10,000 42.6 -> 49.0, 4,096 23.8 -> 33.1 -- a round of these tiles is 50 us whatever fills it, so only from 13,000 rows
+    static const int wide_min = tune_int("MMF_DH_64X128", 13000);
+    if (wide_min > 0 && p.N >= wide_min && p.fused_prep && p.g.gated && p.H % 128 == 0 && (2 * p.g.D / KC) % 4 == 0) {
+      using T2 = Tile<64, 128, 2, 2, true, false>;
+      p.mt_count = (int)((p.N + 63) / 64); p.nt_count = p.H / 128;
+      p.deep = 1;
+      return launch_tiled_extra<T2>("bwd_dh_kernel", bwd_dh_kernel<T2, true>, p, grid_for_tiles(p.mt_count, p.nt_count),
+                                    (3 * T2::BM + 16) * 4, st);
+    }
+  }
   using T = Tile<64, 64, 2, 2, true, false>;
   p.mt_count = (int)((p.N + 63) / 64); p.nt_count = (p.H + 63) / 64;
   static const int env_deep = tune_int("MMF_DEEP", 1);     // A/B switch

@@ -146,6 +146,9 @@ def test_path_ragged_sizes(N, gated):
     (23333, True, True, True, "small"),      # gated + attention dropout: the K-dh variant that keeps its run-time switches
     (19999, False, True, True, "small"),     # ungated + attention dropout
     (17011, True, False, True, "big"),       # 1024 / 512 / 384: two column tiles per row tile, three gate tiles in K-tn
+    (14011, True, False, True, "small"),     # 13,000 - 16,383 rows: K-dh on 64 x 128 tiles (K-prep inside, deep prefetch), ragged
+    (15003, True, True, True, "small"),      # the same with attention dropout
+    (13999, True, False, True, "big"),       # H = 512: four 128-column tiles per row tile
 ])
 def test_path_ragged_wide_tiles(N, gated, dropout, train, size, monkeypatch):
     """The large-bag kernels (wide row tiles with the fused K-prep, the 256x256 split-K tile with its permuted
