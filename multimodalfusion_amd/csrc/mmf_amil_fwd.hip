@@ -37,7 +37,8 @@ __device__ inline float apply_act(float v, int act) {
 // ACT = -1: any activation, decided per element (the rarely used tanh / sigmoid / SELU projections).
 // K-split launches: where the last-arriving workgroup of a tile finds the tile's partial sums (LinearParams::kpart)
 struct PartSrc {
-  rsrc_t rs;            // the whole kpart buffer
+  unsigned bytes;       // size of the whole kpart buffer (the buffer resource is rebuilt where it is used: kept in the
+                        // struct it lived in scratch)
   unsigned base;        // byte offset of this tile's first partial
   unsigned slab;        // bytes per partial tile (BM x BN floats)
   int S;                // partials per tile
@@ -45,7 +46,7 @@ struct PartSrc {
 
 template <class T, int ACT, bool DROP>
 __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], f32x4acc (*acch)[2], float* lds,
-                                       int row0, int col0, const PartSrc* ps = nullptr) {
+                                       int row0, int col0, const PartSrc ps = PartSrc{}) {
 #ifdef MMF_DIAG_NOEPI         /* diagnostic build: main loop only (results are wrong) */
   {
     float t = 0.f;
@@ -104,12 +105,13 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
       if ((int64_t)rb16 * 16 < p.M && (int)(cb * 32) < p.N) p.relu_bits[(rb16 * (size_t)(p.N >> 5) + cb) * 8 + (lane & 7)] = mine;
     }
   };
-  if (ps) {
+  if (ps.S > 0) {
     // the tile's sum comes from memory, already row-major: partial s of the tile, rows r + 8 t, columns c .. c + 3 of this
     // lane -- added in split order (bit-reproducible); the loads of block b + 1 are issued before block b's stores
     const int wave = threadIdx.x >> 6, wm = wave / T::WN, wn = wave % T::WN;
     const int rr = lane >> 3, c4 = lane & 7;
     constexpr int NBLK = T::MB * T::NB;
+    const rsrc_t prs = make_rsrc(p.kpart, ps.bytes);
     float4 buf[2][4];
     auto fetch = [&](int b, int rows4, float4 (&v)[4]) {
       const int mb = b / T::NB, nb = b % T::NB;
@@ -117,10 +119,10 @@ __device__ inline void linear_epilogue(const LinearParams& p, f32x16 (&acc)[T::M
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (t >= rows4) break;
-        const unsigned o = ps->base + (unsigned)((r + 8 * t) * T::BN + c) * 4u;
-        float4 a = bld4_dev(ps->rs, o, 0);
-        for (int k = 1; k < ps->S; ++k) {
-          const float4 q = bld4_dev(ps->rs, o, (unsigned)k * ps->slab);
+        const unsigned o = ps.base + (unsigned)((r + 8 * t) * T::BN + c) * 4u;
+        float4 a = bld4_dev(prs, o, 0);
+        for (int k = 1; k < ps.S; ++k) {
+          const float4 q = bld4_dev(prs, o, (unsigned)k * ps.slab);
           a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
         }
         v[t] = a;
@@ -166,14 +168,15 @@ template <class T>
 __device__ inline bool ksplit_publish(const LinearParams& p, f32x16 (&acc)[T::MB][T::NB], f32x4acc (*acch)[2], float* lds,
                                       int tile, int ks, PartSrc& ps) {
   const int S = p.ksplit;
-  ps.rs = make_rsrc(p.kpart, (unsigned)((size_t)p.mt_count * p.nt_count * S * T::BM * T::BN * 4u));
+  ps.bytes = (unsigned)((size_t)p.mt_count * p.nt_count * S * T::BM * T::BN * 4u);
+  const rsrc_t prs = make_rsrc(p.kpart, ps.bytes);
   ps.slab = (unsigned)(T::BM * T::BN * 4);
   ps.base = (unsigned)tile * (unsigned)S * ps.slab;
   ps.S = S;
   const unsigned mine = ps.base + (unsigned)ks * ps.slab;
   epilogue_rows<T>(acc, lds, [&](int mb, int nb, int r, int c, const float4 (&v)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bst4_dev(ps.rs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
+    for (int t = 0; t < 4; ++t) bst4_dev(prs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
   });
   if constexpr (T::HALF) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / T::WN, wn = wave % T::WN;
@@ -184,7 +187,7 @@ __device__ inline bool ksplit_publish(const LinearParams& p, f32x16 (&acc)[T::MB
       transpose_half(acch[nb][0], acch[nb][1], blk, lane, v);
       const int r = wm * (T::BM / T::WM) + T::MB * 32 + (lane >> 3), c = (wn * T::NB + nb) * 32 + 4 * (lane & 7);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bst4_dev(ps.rs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
+      for (int t = 0; t < 2; ++t) bst4_dev(prs, mine + (unsigned)((r + 8 * t) * T::BN + c) * 4u, 0, v[t]);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial rows have reached device scope
@@ -230,11 +233,9 @@ __global__ __launch_bounds__(T::NT) void linear_nt_kernel(LinearParams p) {
 #ifdef MMF_STAMPS
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], k0 - kernel_t0);     // entry -> loaders initialised
 #endif
-  PartSrc part;
-  const PartSrc* ps = nullptr;
+  PartSrc ps{};                              // S = 0: the epilogue takes the tile from the accumulators
   if (S > 1) {
-    if (!ksplit_publish<T>(p, acc, acch, lds, mt * p.nt_count + nt, ks, part)) return;
-    ps = &part;
+    if (!ksplit_publish<T>(p, acc, acch, lds, mt * p.nt_count + nt, ks, ps)) return;
   }
   const bool drop = p.drop_p > 0.f;
   if (p.act == ACT_RELU) {
