@@ -7,7 +7,7 @@
 //
 // The reference spends ~20 framework launches on this step (three addmm / selu / alpha-dropout forward, a Python double
 // loop for the risk-set matrix, the same again backward); round 3 of this repo spent 9 (three dense forward, Cox, three
-// dense backward, an H2D copy and a fill: 82 us of GPU time, 0.29 ms with the host's issue time).  Here: 32 workgroups.
+// dense backward, an H2D copy and a fill: 82 us of GPU time, 0.29 ms with the host's issue time).  Here: 32 workgroups (64 for batches of 129 - 256 rows).
 // The step is latency, not throughput (52 MFLOP): what counts is the number of dependent global round trips, so
 //   phase 1  rows:   workgroup j owns R batch rows -- both SNN blocks and the classifier for those rows, nothing leaves the CU
 //                    but the saved layer outputs (y0, y1) and the risks;
@@ -29,8 +29,8 @@ namespace mmf {
 constexpr float MX_SELU_ALPHA = 1.6732632423543772f;
 constexpr float MX_SELU_SCALE = 1.0507009873554805f;
 constexpr int MX_H = 256;            // both hidden widths of the `small` omic net (model_genomic.py:17)
-constexpr int MX_NW = 32;            // workgroups
-constexpr int MX_NS = MX_H / MX_NW;  // output features per workgroup in phase 4
+constexpr int MX_R = 4;              // batch rows per workgroup in phases 1 - 3
+constexpr int MX_NW_MAX = 64;        // workgroups: 32 for B <= 128, 64 for B <= 256 (kernel template parameter NW)
 
 
 __device__ inline float mx_selu(float v) { return MX_SELU_SCALE * (v > 0.f ? v : MX_SELU_ALPHA * (expf(v) - 1.0f)); }
@@ -47,12 +47,12 @@ __device__ inline MxDrop mx_drop(float p) {
   return d;
 }
 
-__device__ inline void mx_grid_barrier(unsigned* cnt) {
+__device__ inline void mx_grid_barrier(unsigned* cnt, int nw) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();                 // release: this workgroup's stores are visible device-wide
     __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)MX_NW) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nw) __builtin_amdgcn_s_sleep(1);
     __threadfence();                 // acquire
   }
   __syncthreads();
@@ -162,8 +162,9 @@ __device__ inline void mx_stage(float* dst, int n, Src&& src) {
 #define MX_STAMP(i)
 #endif
 
-template <int R>
+template <int NW>
 __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p) {
+  constexpr int R = MX_R, MX_NW = NW, MX_NS = MX_H / NW;     // output features per workgroup in phase 4
   extern __shared__ __align__(16) float sm[];
   MX_STAMP(0);
   float* xs = sm;                               // [256][R] layer input of this workgroup's rows
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   __syncthreads();
   if (tid < R && r0 + tid < B) p.risk[r0 + tid] = red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + bcv;
   MX_STAMP(2);
-  mx_grid_barrier(p.bar);
+  mx_grid_barrier(p.bar, MX_NW);
   MX_STAMP(3);
 
   // ---------------- phase 2: Cox over the whole batch, gradient of this workgroup's rows ---------------------------------
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     }
   }
   MX_STAMP(5);
-  mx_grid_barrier(p.bar + 1);
+  mx_grid_barrier(p.bar + 1, MX_NW);
   MX_STAMP(6);
 
   // ---------------- phase 4: weight gradients, 8 output features per workgroup ------------------------------------------
@@ -468,17 +469,17 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
 }
 
-size_t maxnet_step_workspace_floats(int B) { return (size_t)4 * B * MX_H + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW * MX_H; }
+size_t maxnet_step_workspace_floats(int B) { return (size_t)4 * B * MX_H + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW_MAX * MX_H; }
 
 bool maxnet_step_ok(int B, int G, int H0, int H1) { return B >= 1 && B <= 256 && G >= 1 && G <= 256 && H0 == MX_H && H1 == MX_H; }
 
 int launch_maxnet_cox_step(MaxnetStepParams p, hipStream_t st) {
-  const int R = p.B <= 4 * MX_NW ? 4 : 8;
-  const int lds = (256 * R + 256 * MX_WP + 64) * (int)sizeof(float);
-  auto kern = R == 4 ? maxnet_cox_step_kernel<4> : maxnet_cox_step_kernel<8>;
+  const int nw = p.B <= MX_R * 32 ? 32 : 64;       // four batch rows per workgroup
+  const int lds = (256 * MX_R + 256 * MX_WP + 64) * (int)sizeof(float);
+  auto kern = nw == 32 ? maxnet_cox_step_kernel<32> : maxnet_cox_step_kernel<64>;
   if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   ProfScope ps("maxnet_cox_step_kernel", st);
-  hipLaunchKernelGGL(kern, dim3(MX_NW), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(nw), dim3(256), lds, st, p);
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
