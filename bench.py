@@ -538,7 +538,25 @@ def other_configs_leg(dev, steps, warmup, gen):
             kw = dict(rx)
             kw["path_features"] = xp
             kw["genomic_features"] = rn(80)
-            out[f"{tag}_{fusion}"] = both(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
+            res = both(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
+            if fusion == "concat":
+                # what the training-loop mirror runs for this model (utils/core_utils.py: MM_MIL_Attention_fc_surv.nll_step):
+                # the same step as a fixed sequence of C-ABI calls, no autograd graph, one launch for head + loss + their
+                # backward; ms_per_step above is model(**kw) + loss + backward() through autograd
+                params = list(mm.parameters())
+
+                def one_call():
+                    for p in params:
+                        p.grad = None
+                    mm.nll_step(Y, c, alpha=0.0, **kw)
+
+                oc = timeit(one_call)
+                res["autograd_ms_per_step"] = res["ms_per_step"]
+                res["one_call_step_ms_per_step"] = oc["ms_per_step"]
+                res["ms_per_step"], res["bags_per_s"] = oc["ms_per_step"], oc["bags_per_s"]
+                for p in params:
+                    p.grad = None
+            out[f"{tag}_{fusion}"] = res
             del mm
         del xp
     return out

@@ -66,7 +66,9 @@ typedef struct mmf_amil_desc {
                               * By-value seeds are frozen into a captured hipGraph; a graph whose first node bumps this
                               * word draws fresh masks on every replay.  Forward and backward must see the same value. */
   struct mmf_trace* trace;   /* optional kernel trace (mmf_trace_create), or NULL: see "Kernel trace" below */
-  int32_t concurrent;        /* scheduling hint; results do not depend on it.  0: the call has the GPU to itself -- the
+  int32_t concurrent;        /* scheduling hint; results agree to fp32 rounding whatever it is (bit for bit unless the two
+                              * tile plans put a row into a 16-row half block, v_mfma_f32_16x16x4_f32, in one and into a
+                              * 32-row block in the other: same k order, rounded per instruction).  0: the call has the GPU to itself -- the
                               * row-parallel GEMMs take the tile height that finishes ONE bag soonest (208 rows: a 50k
                               * bag on 241 of 256 CUs, one bag per step 0.816 -> 0.801 ms).  1: other bags' kernels run
                               * beside it on other streams (pipeline.BagsInFlight) -- 224-row tiles, which leave 32 CUs
@@ -174,6 +176,15 @@ int mmf_amil_head_forward(const mmf_amil_desc* desc, const void* x, int32_t x_bf
 int mmf_amil_nll_step(const mmf_amil_desc* desc, const void* x, int32_t x_bf16, void* workspace, size_t workspace_bytes,
                       const mmf_surv_head* head, const mmf_nll_target* target, float* A_raw,
                       const mmf_amil_grads* grads, void* stream);
+
+/* The hazard head's training step on a feature vector that is already on the device: what
+ *   `hazards, S, Y_hat = head(classifier(feat)); loss = NLLSurvLoss(alpha)(hazards, S, Y, c); (loss * loss_scale).backward()`
+ * computes between the embedding and the loss (models/model_mm_attention_mil.py:190-191 with fusion = 'concat': feat is the
+ * concatenation of the branch embeddings, which the caller lets the branches write side by side; utils/loss_utils.py:22-39)
+ * in ONE single-workgroup launch: classifier, sigmoid, cumprod, argmax, the loss, dWk / dbk (target->accumulate as above) and
+ * dfeat [F] = d(loss * loss_scale) / d feat, which the caller hands to the branches' backward calls.  F <= 1024, K <= 32. */
+int mmf_surv_head_nll_step(const float* feat, int32_t F, const mmf_surv_head* head, const mmf_nll_target* target,
+                           float* dfeat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Forward-only variants for the inference consumers of the path -- embedding export

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_amil.so")   # override: diagnostic builds only
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -92,6 +92,8 @@ SYMBOLS = {
                                         C.POINTER(SurvHead), C.c_void_p, C.c_void_p, C.c_void_p]),
     "mmf_amil_nll_step": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t,
                                     C.POINTER(SurvHead), C.POINTER(NllTarget), C.c_void_p, C.POINTER(AmilGrads), C.c_void_p]),
+    "mmf_surv_head_nll_step": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SurvHead), C.POINTER(NllTarget), C.c_void_p,
+                                         C.c_void_p]),
     "mmf_amil_infer_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "mmf_amil_infer": (C.c_int, [C.POINTER(AmilDesc), C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -253,5 +255,8 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The raw handle of torch's current HIP stream on the current device.  (torch.cuda.current_stream() builds a Stream
+    object and goes through is_available(), which reads the environment: ~5 us a call, twenty calls in a multimodal step.)"""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    torch.cuda._lazy_init()
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())

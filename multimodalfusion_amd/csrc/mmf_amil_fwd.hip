@@ -1060,6 +1060,16 @@ int launch_pool_merge(PoolParams p, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
 }
 
+// The head tail on a feature vector that is already there (p.M [p.H <= 1024]; the multimodal step: the branches' embeddings
+// side by side): classifier, hazards, nll_surv and its backward down to d(feature), one single-workgroup launch.
+int launch_head_tail(PoolParams p, hipStream_t st) {
+  if (!p.M || !p.tail.Wk || p.H < 1 || p.H > 1024 || p.tail.K < 1 || p.tail.K > 32) return MMF_ERR_SHAPE;
+  p.merge_in_tail = 0;
+  ProfScope ps("head_tail_kernel", st);
+  hipLaunchKernelGGL(head_tail_kernel, dim3(1), dim3(1024), 0, st, p);
+  return hipGetLastError() == hipSuccess ? MMF_OK : MMF_ERR_LAUNCH;
+}
+
 // diagnostic: read and clear this translation unit's phase stamps (zeros unless built with -DMMF_STAMPS)
 void debug_stamps_fwd(unsigned long long* out8) {
 #ifdef MMF_STAMPS

@@ -255,7 +255,7 @@ using namespace mmf;
 
 extern "C" {
 
-int mmf_abi_version(void) { return 10; }
+int mmf_abi_version(void) { return 11; }
 
 const char* mmf_strerror(int code) {
   switch (code) {
@@ -630,6 +630,18 @@ int mmf_amil_nll_step(const mmf_amil_desc* d, const void* x, int32_t x_bf16, voi
   const float* xf = static_cast<const float*>(x);
   if (int e = amil_forward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, stream, false, &tl)) return e;
   return amil_backward_impl(d, xf, workspace, workspace_bytes, nullptr, A_raw, nullptr, nullptr, grads, stream, acc);
+}
+
+int mmf_surv_head_nll_step(const float* feat, int32_t F, const mmf_surv_head* head, const mmf_nll_target* target,
+                           float* dfeat, void* stream) {
+  if (!feat || !target || !dfeat) return MMF_ERR_ARG;
+  if (F < 1 || F > 1024) return MMF_ERR_SHAPE;
+  PoolParams p{};
+  if (int e = head_tail_of(head, target, F, p.tail)) return e;
+  p.tail.dM = dfeat;
+  p.M = const_cast<float*>(feat);        // read only: the launch neither merges nor stores M
+  p.H = F;
+  return launch_head_tail(p, static_cast<hipStream_t>(stream));
 }
 
 // ---- standalone attention scorer: Attn_Net / Attn_Net_Gated .forward(x) -> (A, x) ------------------------------

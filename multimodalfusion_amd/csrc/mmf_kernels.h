@@ -237,6 +237,7 @@ int launch_gate_fwd(GateFwdParams p, hipStream_t st);
 int pool_groups(int64_t N);
 int launch_pool(PoolParams p, hipStream_t st);
 int launch_score_sum(const float* s_part, int n_parts, const float* bc, float* A, int64_t N, hipStream_t st);
+int launch_head_tail(PoolParams p, hipStream_t st);    // head_tail_kernel alone on the feature vector p.M [p.H]
 int launch_pool_merge(PoolParams p, hipStream_t st);   // single-workgroup merge of p.n_groups partials -> M, stats
 int launch_bwd_prep(BwdPrepParams p, hipStream_t st);
 int launch_bwd_dh(BwdDhParams p, hipStream_t st);

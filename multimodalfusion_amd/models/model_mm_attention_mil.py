@@ -115,22 +115,198 @@ class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
     def _side_stream(self, device):
         """A second HIP stream for the small branches (radio stack, omic SNN): they are independent of the pathology
         stack until the fusion, and its big kernels leave CUs idle (224 of 256 at 50k instances), so the small
-        kernels run beside them instead of after them.  Autograd replays each branch on the stream it ran on."""
-        st = self.__dict__.get("_mmf_side")
+        kernels run beside them instead of after them.  Autograd replays each branch on the stream it ran on.
+        One per main stream, chosen by measurement (streams.stream_beside): a pool stream that shares the main stream's
+        hardware queue would run the branches after the stack, not beside it."""
+        from ..streams import stream_beside
+        cur = torch.cuda.current_stream(device)
+        pool = self.__dict__.setdefault("_mmf_side", {})        # not a parameter / buffer: stays out of state_dict
+        st = pool.get(cur.cuda_stream)
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device)
-            self.__dict__["_mmf_side"] = st              # not a parameter / buffer: stays out of state_dict
+            st = pool[cur.cuda_stream] = stream_beside([cur], device)
         return st
+
+    def _fork_ok(self, path_x, min_units=120_000):
+        # worth it only while the step is GPU-bound, i.e. the pathology stack runs for longer than the host needs to
+        # issue the step (~0.9 ms): >= 30k fp32 instances / >= 120k bf16 instances (measured: 50k fp32 1.30 -> 1.07 ms;
+        # 100k bf16 is host-bound and the extra stream calls cost 0.05 ms)
+        return (getattr(self, "mmf_side_stream", True)          # set False on an instance to keep everything on one stream
+                and path_x is not None and path_x.is_cuda and ("radio" in self.mode or "omic" in self.mode)
+                and path_x.shape[0] * (1 if path_x.dtype == torch.bfloat16 else 4) >= min_units)
+
+    def _concat_order(self):
+        has = lambda k: k in self.mode
+        if has("radio") and has("path") and not has("omic"):
+            return ["radio", "path"]
+        if has("radio") and has("omic") and not has("path"):
+            return ["radio", "omic"]
+        if has("omic") and has("path") and not has("radio"):
+            return ["omic", "path"]
+        return ["radio", "path", "omic"]
+
+    def nll_step(self, label, c, alpha=0.0, loss_scale=1.0, grad_out=None, accumulate=None, **kwargs):
+        """Extension of the reference surface (the training-loop mirror uses it, utils/core_utils.py): the whole training
+        step of one patient with fusion='concat' -- what `hazards, S, Y_hat, A_raw = model(**kwargs)`,
+        `loss = NLLSurvLoss(alpha)(hazards=hazards, S=S, Y=label, c=c)`, `(loss * loss_scale).backward()` compute together
+        (models/model_mm_attention_mil.py:128-200 + utils/loss_utils.py:22-39 + autograd), with the same dropout draws --
+        as a fixed sequence of C-ABI calls with no autograd graph: the branches' forward calls (radio and omic on the side
+        stream beside the pathology stack), ONE launch for classifier + hazards + loss + their backward
+        (mmf_surv_head_nll_step; the branches write their embeddings side by side, so the concatenation is never a
+        launch), the branches' backward calls.  Gradients are ADDED to the parameters' .grad (a parameter whose .grad is
+        None receives the fresh buffer, as autograd does) -- or to `grad_out`, tensors in self.parameters() order,
+        overwritten unless `accumulate`.  Returns (hazards, S, Y_hat, A_raw dict, loss, risk), detached."""
+        from ..ops import AmilPoolFn, HandCtx, LinearCatFn, _dense_bwd_raw, _dense_fwd_raw
+        if self.fusion != "concat":
+            raise NotImplementedError("nll_step covers fusion='concat'; the tensor fusion takes forward() + autograd")
+        params = list(self.parameters())
+        if any(not p.requires_grad for p in params):
+            raise RuntimeError("nll_step needs every parameter to require grad")
+        tr = self.training
+        order = self._concat_order()
+        width = {"radio": self.attention_net_radio[0].out_features, "path": self.attention_net_WSI[0].out_features,
+                 "omic": self.fc_omic[-1][0].out_features}
+        off, o = {}, 0
+        for k in order:
+            off[k] = o
+            o += width[k]
+        F = o
+        path_x = kwargs.get("path_features") if "path" in order else None
+        dev = (path_x if path_x is not None else kwargs[self.modalities[0]] if "radio" in order
+               else kwargs["genomic_features"]).device
+        # the side stream costs this step ~0.12 ms of host time (stream switches, four cross-stream waits) and pays from
+        # 20k fp32 rows on (tools/r4_mm_fork.sh: 20k 0.60 -> 0.54 ms, 50k 1.02 -> 0.89; 10k 0.43 -> 0.45; bf16 100k 0.59 -> 0.56)
+        fork = self._fork_ok(path_x, getattr(self, "mmf_fork_min_one_call", 80_000))
+        grads = {}                                   # parameter -> gradient tensor of this step
+
+        def stack_args(seq):
+            lin, att = seq[0], seq[3]
+            gated = isinstance(att, Attn_Net_Gated)
+            Wa, ba, Wb, bb, Wc, bc = att.stack_params()
+            p_h = seq[2].p if tr else 0.0
+            p_att = 0.25 if (tr and att.att_dropout) else 0.0
+            seed = ops.next_dropout_seed() if tr else 0
+            return (lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc), (gated, p_h, p_att, seed)
+
+        def stack_backward(ctx, ps, g):
+            out = AmilPoolFn.backward(ctx, g, None)
+            for p, gr in zip(ps, out[1:9]):
+                if p is not None:
+                    grads[p] = gr
+            return out[0]
+
+        with torch.no_grad():
+            feat = torch.empty((1, F), dtype=torch.float32, device=dev)
+            slot = lambda k: feat[:, off[k]:off[k] + width[k]]
+            if fork:
+                cur = torch.cuda.current_stream(dev)
+                side = self._side_stream(dev)
+                side.wait_stream(cur)
+                branch = lambda: torch.cuda.stream(side)
+            else:
+                import contextlib
+                branch = contextlib.nullcontext
+            A_raw = {}
+            # ---- forward: python order (and with it the dropout-seed order) radio, path, omic as in forward()
+            if "radio" in order:
+                with branch():
+                    xs = [kwargs[m] for m in self.modalities]
+                    ctx_cat = None
+                    if len(xs) > 1:
+                        ctx_cat = HandCtx((True, True) + (False,) * len(xs))
+                        h_radio = LinearCatFn.forward(ctx_cat, self.reduce_dim.weight, self.reduce_dim.bias, *xs)
+                    else:
+                        h_radio = xs[0]
+                    ps_r, cfg = stack_args(self.attention_net_radio)
+                    ctx_r = HandCtx((ctx_cat is not None,) + (True,) * 8 + (False,) * 4)
+                    _, A_raw["radiology"] = AmilPoolFn.forward(ctx_r, h_radio, *ps_r, *cfg, M_out=slot("radio"))
+            if "path" in order:
+                ps_p, cfg = stack_args(self.attention_net_WSI)
+                ctx_p = HandCtx((False,) + (True,) * 8 + (False,) * 4)
+                prev = ops.set_concurrent(True) if fork else None      # see forward(): 224-CU tile plan beside the branches
+                try:
+                    _, A_raw["pathology"] = AmilPoolFn.forward(ctx_p, path_x, *ps_p, *cfg, M_out=slot("path"))
+                finally:
+                    if fork:
+                        ops.set_concurrent(prev)
+            if "omic" in order:
+                with branch():
+                    X = kwargs["genomic_features"]
+                    if X.dim() == 1:
+                        X = X.unsqueeze(0)
+                    seed = ops.next_dropout_seed() if tr else 0
+                    word = ops._seed_word
+                    acts = [ops._f32c(X)]
+                    nblk = len(self.fc_omic)
+                    for i, blk in enumerate(self.fc_omic):
+                        lin, adrop = blk[0], blk[2]
+                        acts.append(_dense_fwd_raw(acts[-1], lin.weight, lin.bias, "selu", "alpha" if tr else "none",
+                                                   adrop.p if tr else 0.0, seed, i, word,
+                                                   out=slot("omic") if i == nblk - 1 else None))
+            if fork:
+                cur.wait_stream(side)
+            # ---- classifier + hazards + loss + their backward: one launch
+            Wk, bk = self.classifier.weight, self.classifier.bias
+            dWk, dbk = torch.empty_like(Wk), torch.empty_like(bk)
+            hazards, S, Y_hat, loss, risk, dfeat = ops.surv_head_nll_step(feat, Wk, bk, label, c, alpha, dWk, dbk,
+                                                                          loss_scale=loss_scale)
+            grads[Wk], grads[bk] = dWk, dbk
+            dslot = lambda k: dfeat[:, off[k]:off[k] + width[k]]
+            if fork:
+                side.wait_stream(cur)
+            # ---- backward: the pathology stack on this stream, the small branches beside it
+            if "path" in order:
+                stack_backward(ctx_p, ps_p, dslot("path"))
+            if "omic" in order:
+                with branch():
+                    g = dslot("omic")
+                    for i in range(nblk - 1, -1, -1):
+                        lin, adrop = self.fc_omic[i][0], self.fc_omic[i][2]
+                        g, dW, db = _dense_bwd_raw(g, acts[i + 1], acts[i], lin.weight, lin.bias is not None, "selu",
+                                                   "alpha" if tr else "none", adrop.p if tr else 0.0, seed, i,
+                                                   need_dx=i > 0, word=word)
+                        grads[lin.weight] = dW
+                        if lin.bias is not None:
+                            grads[lin.bias] = db
+            if "radio" in order:
+                with branch():
+                    dh = stack_backward(ctx_r, ps_r, dslot("radio"))
+                    if ctx_cat is not None:
+                        out = LinearCatFn.backward(ctx_cat, dh)
+                        grads[self.reduce_dim.weight], grads[self.reduce_dim.bias] = out[0], out[1]
+            if fork:
+                cur.wait_stream(side)
+            # ---- hand the gradients over (parameters of branches outside `mode` took no part: no gradient, as in autograd)
+            if grad_out is not None:
+                dst, src = [], []
+                for p, t in zip(params, grad_out):
+                    if p in grads:
+                        dst.append(t)
+                        src.append(grads[p])
+                    elif not accumulate:
+                        t.zero_()
+                if accumulate:
+                    torch._foreach_add_(dst, src)
+                else:
+                    torch._foreach_copy_(dst, src)
+            else:
+                dst, src = [], []
+                for p in params:
+                    g = grads.get(p)
+                    if g is None:
+                        continue
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        dst.append(p.grad)
+                        src.append(g)
+                if dst:
+                    torch._foreach_add_(dst, src)
+        return hazards, S, Y_hat, A_raw, loss, risk
 
     def forward(self, **kwargs):
         A_raw = {}
         path_x = kwargs.get("path_features") if "path" in self.mode else None
-        # worth it only while the step is GPU-bound, i.e. the pathology stack runs for longer than the host needs to
-        # issue the step (~0.9 ms): >= 30k fp32 instances / >= 120k bf16 instances (measured: 50k fp32 1.30 -> 1.07 ms;
-        # 100k bf16 is host-bound and the extra stream calls cost 0.05 ms)
-        fork = (getattr(self, "mmf_side_stream", True)          # set False on an instance to keep everything on one stream
-                and path_x is not None and path_x.is_cuda and ("radio" in self.mode or "omic" in self.mode)
-                and path_x.shape[0] * (1 if path_x.dtype == torch.bfloat16 else 4) >= 120_000)
+        fork = self._fork_ok(path_x)
         if fork:
             cur = torch.cuda.current_stream(path_x.device)
             side = self._side_stream(path_x.device)
@@ -154,7 +330,13 @@ class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
                 M_radio, A_raw["radiology"] = amil_stack(self.attention_net_radio, h_radio, self.training)
                 joined += [M_radio, A_raw["radiology"]]
         if "path" in self.mode:
+            # with the small branches on the side stream the pathology stack plans its wide tiles for 224 CUs (the hint of
+            # mmf_amil_desc::concurrent): the branches' kernels then find CUs while a projection / K-dh launch is resident
+            # instead of waiting for it to drain (as one hipGraph 1.13 -> 1.05 ms, tools/r4_mm_try.sh)
+            prev = ops.set_concurrent(True) if fork else None
             M_path, A_raw["pathology"] = amil_stack(self.attention_net_WSI, kwargs["path_features"], self.training)
+            if fork:
+                ops.set_concurrent(prev)
         if "omic" in self.mode:
             with branch():
                 X = kwargs["genomic_features"]
@@ -169,15 +351,9 @@ class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
             for t in joined:
                 t.record_stream(cur)
 
-        has = lambda k: k in self.mode
-        if has("radio") and has("path") and not has("omic"):
-            v_list = [M_radio, M_path]
-        elif has("radio") and has("omic") and not has("path"):
-            v_list = [M_radio, O]
-        elif has("omic") and has("path") and not has("radio"):
-            v_list = [O, M_path]
-        else:
-            v_list = [M_radio, M_path, O]
+        emb = {"radio": M_radio if "radio" in self.mode else None, "path": M_path if "path" in self.mode else None,
+               "omic": O if "omic" in self.mode else None}
+        v_list = [emb[k] for k in self._concat_order()]
 
         if self.fusion == "tensor":
             seed = ops.next_dropout_seed() if self.training else 0

@@ -59,6 +59,7 @@ def set_trace(handle):
 SYNC_WORDS = 1024
 _sync = {}
 _sync_override = None
+_have_gpu = None          # torch.cuda.is_available(), asked once (it reads the environment on every call)
 
 
 def set_sync_override(words):
@@ -75,28 +76,34 @@ def sync_words(device=None):
     flight) get their own.  None while a stream is being captured without an override (the calls then run unsplit)."""
     if _sync_override is not None:
         return _sync_override
-    if (device is not None and torch.device(device).type != "cuda") or not torch.cuda.is_available():
+    global _have_gpu
+    if device is not None and not isinstance(device, torch.device):
+        device = torch.device(device)
+    if device is not None and device.type != "cuda":
         return None                      # CPU tensors: the call itself raises MmfError (there is no CPU path)
+    if _have_gpu is None:
+        _have_gpu = torch.cuda.is_available()
+    if not _have_gpu:
+        return None
     if torch.cuda.is_current_stream_capturing():
         return None
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    index = torch._C._cuda_getDevice() if device is None or device.index is None else device.index
+    key = (index, torch._C._cuda_getCurrentRawStream(index))
     t = _sync.get(key)
     if t is None:
-        t = _sync[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=dev)
+        t = _sync[key] = torch.zeros(SYNC_WORDS, dtype=torch.int32, device=torch.device("cuda", index))
     return t
 
 
-def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, seed_word):
+def _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, seed_word, concurrent=None):
     sw = sync_words(W1.device if W1 is not None else None)
     return AmilDesc(sync=ptr(sw), sync_words=SYNC_WORDS if sw is not None else 0,
                     N=N, L=L, H=H, D=D, gated=1 if gated else 0,
                     W1=ptr(W1), b1=ptr(b1), Wa=ptr(Wa), ba=ptr(ba),
                     Wb=ptr(Wb) if gated else None, bb=ptr(bb) if gated else None,
                     Wc=ptr(Wc), bc=ptr(bc), p_h=float(p_h), p_att=float(p_att), seed=int(seed) & 0xFFFFFFFF,
-                    seed_dev=ptr(seed_word), trace=_trace, concurrent=_concurrent, gemm=_gemm)
+                    seed_dev=ptr(seed_word), trace=_trace, concurrent=_concurrent if concurrent is None else concurrent,
+                    gemm=_gemm)
 
 
 def next_dropout_seed() -> int:
@@ -122,7 +129,9 @@ class AmilPoolFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed):
+    def forward(ctx, x, W1, b1, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed, M_out=None):
+        # (M_out: only for callers that run the node by hand -- the multimodal step lets the stack write its embedding
+        # straight into its slot of the concatenated feature vector)
         # a bf16 bag selects the bf16-storage kernels (include/mmf_amil.h: mmf_amil_bf16_*); parameters stay fp32
         bf16 = x.dtype == torch.bfloat16
         x = x.contiguous() if bf16 else _f32c(x)
@@ -141,13 +150,14 @@ class AmilPoolFn(torch.autograd.Function):
                          else (l.mmf_amil_workspace_bytes, l.mmf_amil_forward))
         nbytes = ws_fn(N, L, H, D, d.gated)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        M = torch.empty((1, H), dtype=torch.float32, device=x.device)
+        M = torch.empty((1, H), dtype=torch.float32, device=x.device) if M_out is None else M_out
         A_raw = torch.empty((1, N), dtype=torch.float32, device=x.device)
         check(fwd_fn(C.byref(d), ptr(x), ptr(ws), nbytes, ptr(M), ptr(A_raw), stream_ptr()),
               "mmf_amil_bf16_forward" if bf16 else "mmf_amil_forward")
         ctx.bf16 = bf16
         ctx.desc_args = (N, L, H, D, bool(gated), float(p_h), float(p_att), int(seed) & 0xFFFFFFFF)
         ctx.seed_word = word
+        ctx.concurrent = _concurrent          # the backward runs on the autograd thread, after the caller has lowered the hint
         ctx.ws = ws
         ctx.save_for_backward(x, W1, b1, Wa, ba, Wb, bb, Wc, bc, M, A_raw)
         ctx.set_materialize_grads(False)      # an unused output (A_raw, mostly) must not cost a zero-fill launch
@@ -160,7 +170,7 @@ class AmilPoolFn(torch.autograd.Function):
         dev = x.device
         gM = torch.zeros((1, H), dtype=torch.float32, device=dev) if gM is None else _f32c(gM)
         gA = _f32c(gA) if gA is not None else None
-        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, ctx.seed_word)
+        d = _amil_desc(N, L, H, D, gated, W1, b1, Wa, ba, Wb, bb, Wc, bc, p_h, p_att, seed, ctx.seed_word, ctx.concurrent)
         new = lambda ref: torch.empty_like(ref)
         dW1, db1, dWa, dba, dWc, dbc = new(W1), new(b1), new(Wa), new(ba), new(Wc), new(bc)
         dWb, dbb = (new(Wb), new(bb)) if gated else (None, None)
@@ -512,6 +522,54 @@ def nll_surv(hazards, S, Y, c, alpha=0.4, eps=1e-7):
     return NllSurvFn.apply(hazards, S, Y, c, alpha, eps)
 
 
+def surv_head_nll_step(feat, Wk, bk, Y, c, alpha, dWk, dbk, loss_scale=1.0, accumulate=False, eps=1e-7):
+    """Classifier + hazard head + NLLSurvLoss(alpha) + their backward on a feature vector feat [1 x F] (F <= 1024) in ONE
+    launch (mmf_surv_head_nll_step; models/model_mm_attention_mil.py:190-191 + utils/loss_utils.py:22-39): dWk / dbk get
+    the gradient of loss * loss_scale (added when `accumulate`).
+    Returns (hazards [1 x K], S [1 x K], Y_hat [1 x 1], loss (0-dim, unscaled), risk [1], dfeat [1 x F]), detached."""
+    feat, Wk, bk = _f32c(feat), _f32c(Wk), _f32c(bk)
+    F = feat.numel()
+    K = Wk.shape[0]
+    if Wk.shape[1] != F or F > 1024 or K > 32:
+        raise _lib.MmfError("surv_head_nll_step: classifier does not match the feature vector (F <= 1024, K <= 32)")
+    for g_, w_ in ((dWk, Wk), (dbk, bk)):
+        if g_ is None or g_.dtype != torch.float32 or g_.shape != w_.shape or not g_.is_contiguous():
+            raise _lib.MmfError("gradient buffers must be contiguous float32 tensors shaped like their parameters")
+    dev = feat.device
+    if not Y.is_cuda and bool(((Y < 0) | (Y >= K)).any()):
+        raise IndexError(f"nll_surv: label out of range [0, {K})")
+    Y = Y.reshape(1).to(device=dev, dtype=torch.int64)
+    c = c.reshape(1).to(device=dev, dtype=torch.float32)
+    out = torch.empty((3 * K + 2,), dtype=torch.float32, device=dev)       # logits, hazards, S, loss, risk
+    Y_hat = torch.empty((1, 1), dtype=torch.int64, device=dev)
+    dfeat = torch.empty((1, F), dtype=torch.float32, device=dev)
+    hd = SurvHead(Wk=ptr(Wk), bk=ptr(bk), K=K, logits=ptr(out[0:K]), hazards=ptr(out[K:2 * K]), S=ptr(out[2 * K:3 * K]),
+                  Y_hat=ptr(Y_hat), risk=ptr(out[3 * K + 1:]))
+    tg = NllTarget(Y=ptr(Y), c=ptr(c), alpha=float(alpha), eps=float(eps), loss_scale=float(loss_scale),
+                   loss=ptr(out[3 * K:]), dWk=ptr(dWk), dbk=ptr(dbk), accumulate=1 if accumulate else 0)
+    check(lib().mmf_surv_head_nll_step(ptr(feat), F, C.byref(hd), C.byref(tg), ptr(dfeat), stream_ptr()),
+          "mmf_surv_head_nll_step")
+    return (out[K:2 * K].view(1, K), out[2 * K:3 * K].view(1, K), Y_hat, out[3 * K].view(()), out[3 * K + 1:].view(1), dfeat)
+
+
+class HandCtx:
+    """Stands in for the autograd context when a node's forward / backward are run by hand (no graph): the multimodal
+    one-call step drives AmilPoolFn / LinearCatFn directly, on the streams it chooses."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
 class CoxSurvFn(torch.autograd.Function):
     """utils/loss_utils.py:124-139."""
 
@@ -674,10 +732,10 @@ def kron_ones(os_, drop_p=0.0, seed=0, site=0):
 
 
 # ---- raw (no-autograd) launch helpers shared by the fused fusion Function --------------------------------------
-def _dense_fwd_raw(x, W, b, act, kind, p, seed, site, word=None):
+def _dense_fwd_raw(x, W, b, act, kind, p, seed, site, word=None, out=None):
     B, K = x.shape
     N = W.shape[0]
-    y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    y = torch.empty((B, N), dtype=torch.float32, device=x.device) if out is None else out
     check(lib().mmf_dense_forward(ptr(x), ptr(W), ptr(b), B, K, N, ACT[act], DROP_KIND[kind], float(p), seed, site,
                                   ptr(word), ptr(y), stream_ptr()), "mmf_dense_forward")
     return y

@@ -22,7 +22,12 @@ class BagsInFlight:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.device = self.params[0].device if device is None else torch.device(device)
         self.n = max(1, int(n_streams))
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+        # each stream is measured to run beside the ones chosen before it (streams.stream_beside): two pool streams that
+        # share a hardware queue would put the bags back in line, one after the other
+        from .streams import stream_beside
+        self.streams = []
+        for _ in range(self.n):
+            self.streams.append(stream_beside(self.streams, self.device))
         from .dp import flat_layout
         # the layout of optim.FlatAdam / dp.FlatGradBuffer (every tensor on a 16-byte boundary): slots are summed into
         # those buffers, and the kernels of the one-call step store float4s into the slot views

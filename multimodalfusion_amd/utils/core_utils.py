@@ -192,6 +192,29 @@ def _fused_cox_ok(model, loss_fn, feats):
     return x is not None and x.dtype == torch.float32 and model.cox_step_ok(x)
 
 
+def _fused_mm_ok(model, loss_fn, feats):
+    """One patient = one fixed sequence of C-ABI calls without an autograd graph (model.nll_step of the multimodal concat
+    head).  Only where that is exactly what `model(**feats)` + the stock loss would compute: MM_MIL_Attention_fc_surv ITSELF
+    with fusion='concat', the stock NLLSurvLoss, no hooks, every parameter trainable, inputs on the GPU."""
+    from ..models.model_mm_attention_mil import MM_MIL_Attention_fc_surv
+    import torch.nn.modules.module as tm
+    if type(loss_fn) is not NLLSurvLoss or type(model).forward is not MM_MIL_Attention_fc_surv.forward:
+        return False
+    if getattr(model, "fusion", None) != "concat" or not getattr(model, "mmf_one_call_step", True):
+        return False
+    if getattr(getattr(model, "classifier", None), "out_features", 1 << 30) > 32:
+        return False
+    for v in feats.values():
+        if not (torch.is_tensor(v) and v.is_cuda):
+            return False
+    hooked = lambda m: bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None))
+    if any(hooked(m) for m in model.modules()):
+        return False
+    if tm._global_forward_hooks or tm._global_forward_pre_hooks or tm._global_backward_hooks or getattr(tm, "_global_backward_pre_hooks", None):
+        return False
+    return all(p.requires_grad for p in model.parameters())
+
+
 def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer=None, loss_fn=None, reg_fn=None,
                         lambda_reg=0., gc=16, t_bin=None, dp=False, grad_buffer=None, inflight=1):
     """utils/core_utils.py:173-264: same per-bag order (forward, loss, regulariser added AFTER the /gc division,
@@ -250,7 +273,13 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
 
             fused_step = _fused_step_ok(model, loss_fn, feats)
             fused_cox = (not fused_step) and pipe is None and _fused_cox_ok(model, loss_fn, feats)
-            if fused_cox:
+            fused_mm = (not fused_step) and (not fused_cox) and pipe is None and _fused_mm_ok(model, loss_fn, feats)
+            if fused_mm:
+                # the multimodal concat head: branches, one head + loss launch, branch backwards -- no autograd graph; the
+                # gradient of loss / G is already in .grad
+                _, _, _, _, loss, risk = model.nll_step(label, c, alpha=loss_fn.alpha, loss_scale=1.0 / G, **feats)
+                fused_step = True
+            elif fused_cox:
                 # the omic batch: MaxNet forward + Cox + backward in one launch; the gradient of loss / G is already in .grad
                 risk, loss = model.cox_step(feats["genomic_features"], event_time, c, loss_scale=1.0 / G)
                 fused_step = True

@@ -161,7 +161,7 @@ def test_dense_odd_shapes():
 
 def test_mm_side_stream_branches_give_identical_results():
     """Big fp32 path bags run the radio / omic branches on a second HIP stream (model_mm_attention_mil.py: _side_stream);
-    outputs and every gradient must be bit-identical to the single-stream run."""
+    outputs and every gradient must equal the single-stream run (to fp32 rounding where the tile plan differs, see below)."""
     from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
     m = dict(fusion="tensor", mode="radio_path_omic", Np=31000, nr=96, G=80, gate_path=True, gate_radio=True, K=4,
@@ -185,9 +185,14 @@ def test_mm_side_stream_branches_give_identical_results():
         torch.cuda.synchronize()
         outs.append((hz.detach().clone(), {k: v.detach().clone() for k, v in A_raw.items()},
                      {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    # the side-stream run plans the pathology stack's wide tiles for 224 CUs (mmf_amil_desc::concurrent): a row that lands
+    # in a 16-row half block (v_mfma_f32_16x16x4_f32: four k per instruction) in one plan and in a 32-row block (32x32x2) in
+    # the other is summed in the same k order but rounded per instruction -- equal to fp32 rounding, not to the bit; the
+    # radio / omic branches, whose plan does not change, stay bit-identical
     (h1, a1, g1), (h2, a2, g2) = outs
-    assert torch.equal(h1, h2)
-    for k in a1:
-        assert torch.equal(a1[k], a2[k]), k
+    assert torch.allclose(h1, h2, rtol=0, atol=1e-6)
+    assert torch.equal(a1["radiology"], a2["radiology"])
+    assert torch.allclose(a1["pathology"], a2["pathology"], rtol=0, atol=2e-5)
     for k in g1:
-        assert torch.equal(g1[k], g2[k]), k
+        tol = 1e-7 + 2e-5 * float(g2[k].abs().max())
+        assert float((g1[k] - g2[k]).abs().max()) <= tol, k
