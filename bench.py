@@ -498,7 +498,23 @@ def other_configs_leg(dev, steps, warmup, gen):
     torch.manual_seed(1)
     rx = {m: rn(512, 1024) for m in MODS}
     radio = MIL_Attention_fc_surv_radio(n_classes=4).to(dev).train()
-    out["config3_radio_4x512x1024"] = both(radio, rx, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
+    res = both(radio, rx, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
+    # what the training-loop mirror runs for this model (MIL_Attention_fc_surv_radio.nll_step): reduce_dim, the stack + head +
+    # loss + backward as one call, reduce_dim's backward -- no autograd graph; ms_per_step above is the autograd path
+    rparams = list(radio.parameters())
+
+    def radio_one_call():
+        for p in rparams:
+            p.grad = None
+        radio.nll_step(Y, c, alpha=0.0, **rx)
+
+    oc = timeit(radio_one_call)
+    res["autograd_ms_per_step"] = res["ms_per_step"]
+    res["one_call_step_ms_per_step"] = oc["ms_per_step"]
+    res["ms_per_step"], res["bags_per_s"] = oc["ms_per_step"], oc["bags_per_s"]
+    for p in rparams:
+        p.grad = None
+    out["config3_radio_4x512x1024"] = res
     omic = MaxNet(input_dim=36, bag_loss="cox_surv").to(dev).train()
     ot = torch.rand(128, dtype=torch.float64) * 100
     oc = (torch.rand(128, device=dev, generator=gen) < 0.5).float()

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.utils import initialize_weights
-from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, make_amil_stack
+from .model_modules import AMIL_SIZES, amil_stack, amil_stack_head, amil_stack_nll_step, make_amil_stack
 
 
 class MIL_Attention_fc_radio(nn.Module):
@@ -44,6 +44,44 @@ class MIL_Attention_fc_surv_radio(MIL_Attention_fc_radio):
         model_size_radio = "small"              # the reference overrides the argument (:70)
         super().__init__(radio_fusion=radio_fusion, gate_radio=gate_radio, dropout=dropout,
                          model_size_radio=model_size_radio, n_classes=n_classes, modalities=modalities)
+
+    def nll_step(self, label, c, alpha=0.0, loss_scale=1.0, grad_out=None, accumulate=None, **kwargs):
+        """Extension of the reference surface (the training-loop mirror uses it, utils/core_utils.py): forward +
+        NLLSurvLoss(alpha) + backward of one patient without an autograd graph -- what `model(**kwargs)`, the loss and
+        `(loss * loss_scale).backward()` compute together (models/model_attention_mil_radio.py:73-115 +
+        utils/loss_utils.py:22-39), same dropout draw: `reduce_dim` over the modality segments (mmf_linear_forward), the
+        stack + classifier + loss + backward as ONE call that also returns d loss / d(reduce_dim output)
+        (mmf_amil_nll_step), `reduce_dim`'s backward (mmf_linear_backward).  Gradients are ADDED to .grad (fresh buffers
+        where it is None) -- or go to `grad_out`, tensors in self.parameters() order, overwritten unless `accumulate`.
+        Returns (hazards, S, Y_hat, A_raw, loss, risk), detached."""
+        from ..ops import HandCtx, LinearCatFn
+        if any(not p.requires_grad for p in self.parameters()):
+            raise RuntimeError("nll_step needs every parameter of the head to require grad")
+        bags = [kwargs[m] for m in self.modalities]
+        many = len(bags) > 1
+        with torch.no_grad():
+            if many:
+                ctx = HandCtx((True, True) + (False,) * len(bags))
+                x = LinearCatFn.forward(ctx, self.reduce_dim.weight, self.reduce_dim.bias, *bags)
+                dx = torch.empty_like(x)
+            else:
+                x, dx = bags[0], None
+            head_out = None if grad_out is None else list(grad_out)[2 if many else 0:]
+            out = amil_stack_nll_step(self.attention_net_radio, self.classifier, x, self.training, label, c, alpha,
+                                      loss_scale, head_out, accumulate, dx_out=dx)
+            if many:
+                dW, db = LinearCatFn.backward(ctx, dx)[:2]
+                W, b = self.reduce_dim.weight, self.reduce_dim.bias
+                if grad_out is not None:
+                    gW, gb = list(grad_out)[:2]
+                    (gW.add_(dW), gb.add_(db)) if accumulate else (gW.copy_(dW), gb.copy_(db))
+                else:
+                    for p, g in ((W, dW), (b, db)):
+                        if p.grad is None:
+                            p.grad = g
+                        else:
+                            p.grad.add_(g)
+        return out
 
     def forward(self, **kwargs):
         bags = [kwargs[m] for m in self.modalities]

@@ -265,13 +265,16 @@ def amil_stack(seq, x, training):
     return ops.amil_pool(x, lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc, gated, p_h, p_att, seed)
 
 
-def amil_stack_nll_step(seq, classifier, x, training, Y, c, alpha, loss_scale=1.0, grad_out=None, accumulate=None):
+def amil_stack_nll_step(seq, classifier, x, training, Y, c, alpha, loss_scale=1.0, grad_out=None, accumulate=None,
+                        dx_out=None):
     """The whole training step of one bag -- stack, classifier / hazard head, nll_surv and the backward -- as ONE C-ABI
     call (ops.amil_nll_step), gradients of loss * loss_scale ADDED to the parameters' .grad exactly as
     `(loss * loss_scale).backward()` would (parameters whose .grad is None get a fresh buffer, as autograd does; when
     all of them are None the kernels write instead of accumulate and nothing is zero-filled).
     grad_out: instead of .grad, a list of gradient tensors in the order of [*seq.parameters(), *classifier.parameters()]
     (pipeline.BagsInFlight hands in views of a stream's gradient slot) with `accumulate` said explicitly.
+    dx_out: an [N x L] fp32 tensor that receives the gradient with respect to the bag (overwritten), for a head whose bag
+    is itself computed (the radio head's reduce_dim).
     Returns (hazards, S, Y_hat, A_raw, loss, risk), all detached."""
     import torch
     from .. import ops
@@ -301,7 +304,7 @@ def amil_stack_nll_step(seq, classifier, x, training, Y, c, alpha, loss_scale=1.
     with torch.no_grad():
         return ops.amil_nll_step(x, (lin.weight, lin.bias, Wa, ba, Wb, bb, Wc, bc), classifier.weight, classifier.bias,
                                  gated, Y, c, alpha, grads, loss_scale=loss_scale, accumulate=accumulate,
-                                 p_h=p_h, p_att=p_att, seed=seed)
+                                 p_h=p_h, p_att=p_att, seed=seed, dx=dx_out)
 
 
 def amil_stack_head(seq, classifier, x, training):

@@ -295,8 +295,10 @@ class AmilHeadFn(torch.autograd.Function):
 
 
 def amil_nll_step(x, stack, Wk, bk, gated, Y, c, alpha, grads, loss_scale=1.0, accumulate=False, p_h=0.0, p_att=0.0,
-                  seed=0, eps=1e-7):
-    """One bag's whole training step in ONE C-ABI call (include/mmf_amil.h: mmf_amil_nll_step): attention stack +
+                  seed=0, eps=1e-7, dx=None):
+    """(dx: optional [N x L] fp32 tensor that receives d(loss * loss_scale)/dx -- the radio head, whose bag is
+    reduce_dim's output.)
+    One bag's whole training step in ONE C-ABI call (include/mmf_amil.h: mmf_amil_nll_step): attention stack +
     classifier / hazard head + nll_surv + backward.  No autograd graph is built.
 
     stack = (W1, b1, Wa, ba, Wb, bb, Wc, bc); grads = the matching gradient tensors (dW1, db1, dWa, dba, dWb, dbb, dWc,
@@ -335,7 +337,9 @@ def amil_nll_step(x, stack, Wk, bk, gated, Y, c, alpha, grads, loss_scale=1.0, a
     tg = NllTarget(Y=ptr(Y), c=ptr(c), alpha=float(alpha), eps=float(eps), loss_scale=float(loss_scale),
                    loss=ptr(out[3 * K:]), dWk=ptr(dWk), dbk=ptr(dbk), accumulate=1 if accumulate else 0)
     g = AmilGrads(dW1=ptr(dW1), db1=ptr(db1), dWa=ptr(dWa), dba=ptr(dba), dWb=ptr(dWb) if gated else None,
-                  dbb=ptr(dbb) if gated else None, dWc=ptr(dWc), dbc=ptr(dbc), dx=None)
+                  dbb=ptr(dbb) if gated else None, dWc=ptr(dWc), dbc=ptr(dbc), dx=ptr(dx))
+    if dx is not None and (bf16 or dx.dtype != torch.float32 or dx.shape != x.shape or not dx.is_contiguous()):
+        raise _lib.MmfError("dx must be a contiguous float32 tensor shaped like an fp32 bag")
     check(l.mmf_amil_nll_step(C.byref(d), ptr(x), 1 if bf16 else 0, ptr(ws), nbytes, C.byref(hd), C.byref(tg),
                               ptr(A_raw), C.byref(g), stream_ptr()), "mmf_amil_nll_step")
     return (out[K:2 * K].view(1, K), out[2 * K:3 * K].view(1, K), Y_hat, A_raw, out[3 * K].view(()), out[3 * K + 1:].view(1))

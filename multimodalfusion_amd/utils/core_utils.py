@@ -192,6 +192,30 @@ def _fused_cox_ok(model, loss_fn, feats):
     return x is not None and x.dtype == torch.float32 and model.cox_step_ok(x)
 
 
+def _fused_radio_ok(model, loss_fn, feats):
+    """The radiology head's step without an autograd graph (model.nll_step: reduce_dim, then stack + head + loss + backward
+    in one call, then reduce_dim's backward).  Only where that is exactly what `model(**feats)` + the stock loss would
+    compute: MIL_Attention_fc_surv_radio ITSELF, the stock NLLSurvLoss, fp32 2-D modality bags of one shape on the GPU, no
+    hooks, every parameter trainable."""
+    from ..models.model_attention_mil_radio import MIL_Attention_fc_surv_radio
+    import torch.nn.modules.module as tm
+    if type(loss_fn) is not NLLSurvLoss or type(model).forward is not MIL_Attention_fc_surv_radio.forward:
+        return False
+    if not getattr(model, "mmf_one_call_step", True) or getattr(model.classifier, "out_features", 1 << 30) > 32:
+        return False
+    bags = [feats.get(m) for m in model.modalities]
+    if any(not (torch.is_tensor(b) and b.is_cuda and b.dim() == 2 and b.dtype == torch.float32) for b in bags):
+        return False
+    if any(b.shape != bags[0].shape for b in bags):
+        return False
+    hooked = lambda m: bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None))
+    if any(hooked(m) for m in model.modules()):
+        return False
+    if tm._global_forward_hooks or tm._global_forward_pre_hooks or tm._global_backward_hooks or getattr(tm, "_global_backward_pre_hooks", None):
+        return False
+    return all(p.requires_grad for p in model.parameters())
+
+
 def _fused_mm_ok(model, loss_fn, feats):
     """One patient = one fixed sequence of C-ABI calls without an autograd graph (model.nll_step of the multimodal concat
     head).  Only where that is exactly what `model(**feats)` + the stock loss would compute: MM_MIL_Attention_fc_surv ITSELF
@@ -274,7 +298,12 @@ def train_loop_survival(epoch, model, loader, optimizer, n_classes, mode, writer
             fused_step = _fused_step_ok(model, loss_fn, feats)
             fused_cox = (not fused_step) and pipe is None and _fused_cox_ok(model, loss_fn, feats)
             fused_mm = (not fused_step) and (not fused_cox) and pipe is None and _fused_mm_ok(model, loss_fn, feats)
-            if fused_mm:
+            fused_radio = (not fused_step) and (not fused_cox) and (not fused_mm) and pipe is None \
+                and _fused_radio_ok(model, loss_fn, feats)
+            if fused_radio:
+                _, _, _, _, loss, risk = model.nll_step(label, c, alpha=loss_fn.alpha, loss_scale=1.0 / G, **feats)
+                fused_step = True
+            elif fused_mm:
                 # the multimodal concat head: branches, one head + loss launch, branch backwards -- no autograd graph; the
                 # gradient of loss / G is already in .grad
                 _, _, _, _, loss, risk = model.nll_step(label, c, alpha=loss_fn.alpha, loss_scale=1.0 / G, **feats)

@@ -37,6 +37,13 @@ def step():
     loss_of(model(**kw)).backward()
 
 
+if what == "radio" and os.environ.get("MMF_RADIO_AUTOGRAD") != "1":     # the loop mirror's step for this model: no autograd graph
+    def step():
+        for p in params:
+            p.grad = None
+        model.nll_step(Y, c, alpha=0.0, **kw)
+
+
 if what == "omic":          # what the training-loop mirror runs for this model: the one-launch step (MaxNet.cox_step)
     ot_dev = ot.to(dev)
     x_omic = kw["genomic_features"]
