@@ -555,7 +555,7 @@ def other_configs_leg(dev, steps, warmup, gen):
             kw["path_features"] = xp
             kw["genomic_features"] = rn(80)
             res = both(mm, kw, lambda r: nll(hazards=r[0], S=r[1], Y=Y, c=c))
-            if fusion == "concat":
+            if True:
                 # what the training-loop mirror runs for this model (utils/core_utils.py: MM_MIL_Attention_fc_surv.nll_step):
                 # the same step as a fixed sequence of C-ABI calls, no autograd graph, one launch for head + loss + their
                 # backward; ms_per_step above is model(**kw) + loss + backward() through autograd

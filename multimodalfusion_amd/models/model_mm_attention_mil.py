@@ -146,18 +146,19 @@ class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
 
     def nll_step(self, label, c, alpha=0.0, loss_scale=1.0, grad_out=None, accumulate=None, **kwargs):
         """Extension of the reference surface (the training-loop mirror uses it, utils/core_utils.py): the whole training
-        step of one patient with fusion='concat' -- what `hazards, S, Y_hat, A_raw = model(**kwargs)`,
+        step of one patient (fusion='concat'; fusion='tensor' in the heads' configuration) -- what `hazards, S, Y_hat, A_raw = model(**kwargs)`,
         `loss = NLLSurvLoss(alpha)(hazards=hazards, S=S, Y=label, c=c)`, `(loss * loss_scale).backward()` compute together
         (models/model_mm_attention_mil.py:128-200 + utils/loss_utils.py:22-39 + autograd), with the same dropout draws --
         as a fixed sequence of C-ABI calls with no autograd graph: the branches' forward calls (radio and omic on the side
         stream beside the pathology stack), ONE launch for classifier + hazards + loss + their backward
         (mmf_surv_head_nll_step; the branches write their embeddings side by side, so the concatenation is never a
-        launch), the branches' backward calls.  Gradients are ADDED to the parameters' .grad (a parameter whose .grad is
+        launch; with the tensor fusion the XlinearFusion block and classifier[0] run in front of it), the branches'
+        backward calls.  Gradients are ADDED to the parameters' .grad (a parameter whose .grad is
         None receives the fresh buffer, as autograd does) -- or to `grad_out`, tensors in self.parameters() order,
         overwritten unless `accumulate`.  Returns (hazards, S, Y_hat, A_raw dict, loss, risk), detached."""
         from ..ops import AmilPoolFn, HandCtx, LinearCatFn, _dense_bwd_raw, _dense_fwd_raw
-        if self.fusion != "concat":
-            raise NotImplementedError("nll_step covers fusion='concat'; the tensor fusion takes forward() + autograd")
+        if self.fusion == "tensor" and not (self.mm.skip and len(self._concat_order()) * self.mm.reduce[0][0][0].weight.shape[0] <= 384):
+            raise NotImplementedError("nll_step covers the XlinearFusion configuration the heads use (skip, one patient)")
         params = list(self.parameters())
         if any(not p.requires_grad for p in params):
             raise RuntimeError("nll_step needs every parameter to require grad")
@@ -244,13 +245,44 @@ class MM_MIL_Attention_fc_surv(MM_MIL_Attention_fc):
                                                    out=slot("omic") if i == nblk - 1 else None))
             if fork:
                 cur.wait_stream(side)
-            # ---- classifier + hazards + loss + their backward: one launch
-            Wk, bk = self.classifier.weight, self.classifier.bias
-            dWk, dbk = torch.empty_like(Wk), torch.empty_like(bk)
-            hazards, S, Y_hat, loss, risk, dfeat = ops.surv_head_nll_step(feat, Wk, bk, label, c, alpha, dWk, dbk,
-                                                                          loss_scale=loss_scale)
-            grads[Wk], grads[bk] = dWk, dbk
-            dslot = lambda k: dfeat[:, off[k]:off[k] + width[k]]
+            if self.fusion == "concat":
+                # ---- classifier + hazards + loss + their backward: one launch on the branches' slots
+                Wk, bk = self.classifier.weight, self.classifier.bias
+                dWk, dbk = torch.empty_like(Wk), torch.empty_like(bk)
+                hazards, S, Y_hat, loss, risk, dfeat = ops.surv_head_nll_step(feat, Wk, bk, label, c, alpha, dWk, dbk,
+                                                                              loss_scale=loss_scale)
+                grads[Wk], grads[bk] = dWk, dbk
+                dslot = lambda k: dfeat[:, off[k]:off[k] + width[k]]
+            else:
+                # ---- XlinearFusion (one node's forward / backward bodies, run by hand), classifier[0] + ReLU + Dropout,
+                # then classifier[3] + hazards + loss + their backward in one launch (forward() lines 182-188)
+                from ..ops import XFusionFn
+                seed_f = ops.next_dropout_seed() if tr else 0
+                word_f = ops._seed_word
+                fus = self.mm
+                weights = []
+                for i in range(len(order)):
+                    for lin in (fus.reduce[i][0][0], fus.reduce[i][1][0], fus.reduce[i][2][0]):
+                        weights += [lin.weight, lin.bias]
+                weights += [fus.encoder1[0].weight, fus.encoder1[0].bias, fus.encoder2[0].weight, fus.encoder2[0].bias]
+                p_f = fus.dropout_rate if tr else 0.0
+                ctx_x = HandCtx((False,) * 3 + (True,) * (len(order) + len(weights)))
+                MMv = XFusionFn.forward(ctx_x, len(order), p_f, seed_f, *[slot(k) for k in order], *weights)
+                c0, c3 = self.classifier[0], self.classifier[3]
+                p_c = self.classifier[2].p if tr else 0.0
+                kind_c = "dropout" if tr else "none"
+                hid = _dense_fwd_raw(MMv, c0.weight, c0.bias, "relu", kind_c, p_c, seed_f & 0xFFFFFFFF, 11, word_f)
+                dWk, dbk = torch.empty_like(c3.weight), torch.empty_like(c3.bias)
+                hazards, S, Y_hat, loss, risk, dhid = ops.surv_head_nll_step(hid, c3.weight, c3.bias, label, c, alpha,
+                                                                             dWk, dbk, loss_scale=loss_scale)
+                grads[c3.weight], grads[c3.bias] = dWk, dbk
+                dMM, grads[c0.weight], grads[c0.bias] = _dense_bwd_raw(dhid, hid, MMv, c0.weight, True, "relu", kind_c, p_c,
+                                                                       seed_f & 0xFFFFFFFF, 11, word=word_f)
+                outx = XFusionFn.backward(ctx_x, dMM)
+                dvs = dict(zip(order, outx[3:3 + len(order)]))
+                for p_, g_ in zip(weights, outx[3 + len(order):]):
+                    grads[p_] = g_
+                dslot = lambda k: dvs[k]
             if fork:
                 side.wait_stream(cur)
             # ---- backward: the pathology stack on this stream, the small branches beside it

@@ -219,14 +219,23 @@ def _fused_radio_ok(model, loss_fn, feats):
 def _fused_mm_ok(model, loss_fn, feats):
     """One patient = one fixed sequence of C-ABI calls without an autograd graph (model.nll_step of the multimodal concat
     head).  Only where that is exactly what `model(**feats)` + the stock loss would compute: MM_MIL_Attention_fc_surv ITSELF
-    with fusion='concat', the stock NLLSurvLoss, no hooks, every parameter trainable, inputs on the GPU."""
+    (concat fusion, or the tensor fusion as the heads configure it), the stock NLLSurvLoss, no hooks, every parameter trainable, inputs on the GPU."""
     from ..models.model_mm_attention_mil import MM_MIL_Attention_fc_surv
     import torch.nn.modules.module as tm
     if type(loss_fn) is not NLLSurvLoss or type(model).forward is not MM_MIL_Attention_fc_surv.forward:
         return False
-    if getattr(model, "fusion", None) != "concat" or not getattr(model, "mmf_one_call_step", True):
+    if not getattr(model, "mmf_one_call_step", True):
         return False
-    if getattr(getattr(model, "classifier", None), "out_features", 1 << 30) > 32:
+    fusion = getattr(model, "fusion", None)
+    if fusion == "concat":
+        head = model.classifier
+    elif fusion == "tensor":
+        head = model.classifier[3]
+        if not (model.mm.skip and len(model._concat_order()) * model.mm.reduce[0][0][0].weight.shape[0] <= 384):
+            return False
+    else:
+        return False
+    if head.out_features > 32:
         return False
     for v in feats.values():
         if not (torch.is_tensor(v) and v.is_cuda):

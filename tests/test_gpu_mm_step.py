@@ -1,4 +1,4 @@
-"""The multimodal concat head's one-call training step (MM_MIL_Attention_fc_surv.nll_step; mmf_surv_head_nll_step) against the
+"""The multimodal head's (concat and tensor fusion) one-call training step (MM_MIL_Attention_fc_surv.nll_step; mmf_surv_head_nll_step) against the
 fp64 oracle / the reference-generated fixtures and against the autograd path it replaces (models/model_mm_attention_mil.py:
 128-200 + utils/loss_utils.py:22-39 of the reference)."""
 import numpy as np
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _model(m, sd=None, **kw):
     from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
-    model = MM_MIL_Attention_fc_surv(input_dim=m["G"], radio_fusion="concat", fusion="concat", gate=True,
+    model = MM_MIL_Attention_fc_surv(input_dim=m["G"], radio_fusion="concat", fusion=m["fusion"], gate=True,
                                      gate_path=m.get("gate_path", True), gate_omic=True, gate_radio=m.get("gate_radio", True),
                                      dropout=m.get("dropout", False), n_classes=m["K"], mode=m["mode"], **kw)
     return _load(model, sd) if sd is not None else model.to(DEV)
@@ -33,12 +33,10 @@ def _step(model, kw, m, **extra):
     return model.nll_step(Y, c, alpha=m["alpha"], **extra, **kw)
 
 
-def test_mm_step_golden_concat_cases(golden):
+def test_mm_step_golden_cases(golden):
     g = golden("mm")
     n = 0
     for name, m in g.meta.items():
-        if m["fusion"] != "concat":
-            continue
         n += 1
         sd, kw = _inputs(m)
         model = _model(m, sd).eval()
@@ -55,14 +53,15 @@ def test_mm_step_golden_concat_cases(golden):
     assert n >= 1
 
 
+@pytest.mark.parametrize("fusion", ["concat", "tensor"])
 @pytest.mark.parametrize("mode,Np,dropout", [("radio_path_omic", 700, True), ("radio_path_omic", 31000, True),
                                              ("path_omic", 31000, False), ("radio_path", 900, True), ("radio_omic", 0, True)])
-def test_mm_step_equals_autograd_path(mode, Np, dropout):
+def test_mm_step_equals_autograd_path(mode, Np, dropout, fusion):
     """Same seeds -> same dropout draws: outputs and every gradient agree with model(**kw) + loss + backward to fp32 rounding
     of the head (one fused launch instead of three), in train mode, with and without the side stream (31000 rows fork)."""
     from multimodalfusion_amd import ops
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
-    m = dict(fusion="concat", mode=mode, Np=max(Np, 8), nr=64, G=80, gate_path=True, gate_radio=True, K=4, seed=11, x_seed=12,
+    m = dict(fusion=fusion, mode=mode, Np=max(Np, 8), nr=64, G=80, gate_path=True, gate_radio=True, K=4, seed=11, x_seed=12,
              y=2, c=0, alpha=0.3, bias_std=0.02, dropout=dropout)
     sd, kw = _inputs(m)
     model = _model(m, sd).train()
@@ -90,8 +89,9 @@ def test_mm_step_equals_autograd_path(mode, Np, dropout):
         assert float((got[k] - r).abs().max()) <= tol, (k, float((got[k] - r).abs().max()), tol)
 
 
-def test_mm_step_accumulates_and_fills_grad_out():
-    m = dict(fusion="concat", mode="radio_path_omic", Np=500, nr=48, G=80, gate_path=True, gate_radio=False, K=4, seed=3,
+@pytest.mark.parametrize("fusion", ["concat", "tensor"])
+def test_mm_step_accumulates_and_fills_grad_out(fusion):
+    m = dict(fusion=fusion, mode="radio_path_omic", Np=500, nr=48, G=80, gate_path=True, gate_radio=False, K=4, seed=3,
              x_seed=4, y=0, c=1, alpha=0.0, bias_std=0.02)
     sd, kw = _inputs(m)
     model = _model(m, sd).eval()
@@ -135,9 +135,6 @@ def test_mm_step_bf16_path_bag_and_bit_reproducible():
 
 def test_mm_step_rejects_what_it_does_not_cover():
     from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
-    model = MM_MIL_Attention_fc_surv(input_dim=80, fusion="tensor", n_classes=4).to(DEV)
-    with pytest.raises(NotImplementedError):
-        model.nll_step(torch.tensor([1]), torch.tensor([0.0]), path_features=torch.zeros(8, 1024, device=DEV))
     model = MM_MIL_Attention_fc_surv(input_dim=80, fusion="concat", n_classes=4).to(DEV)
     model.classifier.bias.requires_grad_(False)
     with pytest.raises(RuntimeError):
