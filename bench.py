@@ -854,6 +854,14 @@ def main():
                 k3 = max(40, min(k2, int(k2 * 10000 / n2)))
                 d2 = time_steps(make_step(model, x2, dev, None, 1), k3, args.warmup, 1)
                 sweep[str(n2)] = {"ms_per_step": 1e3 * d2 / k3, "frac_fp32_mfma_peak": size_fractions(n2, 1e3 * d2 / k3)["frac_fp32_mfma_peak"]}
+                if n2 <= 24000:
+                    # mid-size bags leave CUs idle one at a time (39 rows per CU at 10k): the aggregate rate with four bags
+                    # in flight on four streams (pipeline.BagsInFlight, a distinct resident bag per stream)
+                    d4 = time_steps(make_step_inflight(model, x2, dev, 1, 4), k3, args.warmup, 1)
+                    sweep[str(n2)]["four_in_flight_ms_per_bag"] = 1e3 * d4 / k3
+                    sweep[str(n2)]["four_in_flight_frac_fp32_mfma_peak"] = size_fractions(n2, 1e3 * d4 / k3)["frac_fp32_mfma_peak"]
+                    for p in model.parameters():
+                        p.grad = None
                 del x2
             out["n_sweep"] = sweep
             out["graphed_small_bags"] = graph_leg(model, dev, args.steps, g)

@@ -889,9 +889,11 @@ int mmf_maxnet_cox_step(const mmf_maxnet_desc* d, const double* times, const flo
   p.loss_scale = loss_scale;
   float* w = static_cast<float*>(workspace);
   const size_t n = (size_t)d->B * 256;
-  p.y0 = w; p.y1 = w + n; p.dp1 = w + 2 * n; p.dp0 = w + 3 * n; p.dr = w + 4 * n;
-  p.stamps = reinterpret_cast<unsigned long long*>(w + 4 * n + (size_t)((d->B + 63) / 64 * 64));      // read by tools/stamps_maxnet.py only
-  p.dwc_part = w + 4 * n + (size_t)((d->B + 63) / 64 * 64) + 32;
+  const size_t nt = (size_t)256 * maxnet_step_dp_pitch(d->B);
+  p.y0 = w; p.y1 = w + n; p.dp1 = w + 2 * n; p.dp0 = p.dp1 + nt; p.dr = p.dp0 + nt;
+  float* after = p.dr + (size_t)((d->B + 63) / 64 * 64);
+  p.stamps = reinterpret_cast<unsigned long long*>(after);      // read by tools/stamps_maxnet.py only
+  p.dwc_part = after + 32;
   p.bar = d->sync;
   p.risk = risk; p.loss = loss;
   p.dW0 = g->dW0; p.db0 = g->db0; p.dW1 = g->dW1; p.db1 = g->db1; p.dWc = g->dWc; p.dbc = g->dbc;

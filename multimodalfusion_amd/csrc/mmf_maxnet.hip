@@ -165,6 +165,7 @@ __device__ inline void mx_stage(float* dst, int n, Src&& src) {
 template <int NW>
 __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p) {
   constexpr int R = MX_R, MX_NW = NW, MX_NS = MX_H / NW;     // output features per workgroup in phase 4
+  constexpr int BP = NW * MX_R;                              // row pitch of the transposed dpre arrays: every workgroup's rows
   extern __shared__ __align__(16) float sm[];
   MX_STAMP(0);
   float* xs = sm;                               // [256][R] layer input of this workgroup's rows
@@ -176,6 +177,10 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   const uint32_t sdev = p.seed_dev ? *p.seed_dev : 0u;
   const MxDrop dr = mx_drop(p.p);
   const uint32_t key0 = p.key0 + sdev, key1 = p.key1 + sdev;
+
+  // the Cox phase's operands that do not depend on the net are requested now: their round trip hides behind phase 1
+  const double t_pre = tid < B ? p.times[tid] : 0.0;
+  const float c_pre = tid < B ? p.c[tid] : 0.f;
 
   // ---------------- phase 1: this workgroup's rows through the net ----------------------------------------------------
   float acc[R], y0d[R], y1d[R];
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   double* tl = reinterpret_cast<double*>(wl + 1280);    // [256] event times
   if (tid < B) {
     const float t = p.risk[tid];
-    th[tid] = t; et[tid] = expf(t); uc[tid] = 1.f - p.c[tid]; tl[tid] = p.times[tid];
+    th[tid] = t; et[tid] = expf(t); uc[tid] = 1.f - c_pre; tl[tid] = t_pre;
   }
   __syncthreads();
   float lterm = 0.f;
@@ -239,6 +244,21 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     const double ti = tl[tid];
     float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
     int j = 0;
+    // 16 risk-set members per pass, their twelve 16-byte LDS reads issued together (four at a time, each read waited for,
+    // was one LDS round trip per member: 16 k of the phase's 19 k cycles)
+    for (; j + 15 < B; j += 16) {
+      double2 t2[8];
+      float4 e4[4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t2[u] = *reinterpret_cast<const double2*>(tl + j + 2 * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e4[u] = *reinterpret_cast<const float4*>(et + j + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d0 += (t2[2 * u].x >= ti) ? e4[u].x : 0.f; d1 += (t2[2 * u].y >= ti) ? e4[u].y : 0.f;
+        d2 += (t2[2 * u + 1].x >= ti) ? e4[u].z : 0.f; d3 += (t2[2 * u + 1].y >= ti) ? e4[u].w : 0.f;
+      }
+    }
     for (; j + 3 < B; j += 4) {
       d0 += (tl[j] >= ti) ? et[j] : 0.f; d1 += (tl[j + 1] >= ti) ? et[j + 1] : 0.f;
       d2 += (tl[j + 2] >= ti) ? et[j + 2] : 0.f; d3 += (tl[j + 3] >= ti) ? et[j + 3] : 0.f;
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   for (int u = 0; u < SG3; ++u) w3[1][u] = p.W1[(size_t)(SG3 + u) * MX_H + tid];
   {
     float wpart = 0.f;                          // this workgroup's share of dWc[k = tid] = sum_b dr[b] y1[b][k]
+    float dd[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
@@ -297,8 +318,13 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
       }
       const float d = red[r] * wcv * dydy * mx_selu_grad_from_y(y);
       dps[tid * R + r] = d;
-      if (r0 + r < B) { p.dp1[(size_t)(r0 + r) * MX_H + tid] = d; wpart += red[r] * y1d[r]; }
+      dd[r] = d;                                // rows beyond the batch: red[r] = 0, so d = 0
+      if (r0 + r < B) wpart += red[r] * y1d[r];
     }
+    // dpre1 / dpre0 leave transposed ([feature][row], pitch BP): phase 4 wants a feature's whole batch column, and this
+    // way it is one contiguous row there instead of a gather of 32-byte pieces
+    static_assert(R == 4, "one float4 per thread");
+    st4(p.dp1 + (size_t)tid * BP + r0, float4{dd[0], dd[1], dd[2], dd[3]});
     p.dwc_part[(size_t)blockIdx.x * MX_H + tid] = wpart;
   }
   __syncthreads();
@@ -329,6 +355,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
         }
       }
     }
+    float d0[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
@@ -338,8 +365,9 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
         dydy = kp ? dr.a : 0.f;
         y = kp ? (y0d[r] - dr.b) / dr.a : 0.f;
       }
-      if (r0 + r < B) p.dp0[(size_t)(r0 + r) * MX_H + tid] = a[r] * dydy * mx_selu_grad_from_y(y);
+      d0[r] = a[r] * dydy * mx_selu_grad_from_y(y);         // rows beyond the batch: a[r] = 0
     }
+    st4(p.dp0 + (size_t)tid * BP + r0, float4{d0[0], d0[1], d0[2], d0[3]});
   }
   MX_STAMP(5);
   mx_grid_barrier(p.bar + 1, MX_NW);
@@ -349,8 +377,9 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   const int n0 = blockIdx.x * MX_NS;
   float* d1s = wl;                              // [B][8] dpre1[:, n0 .. n0 + 7]
   float* d0s = wl + 8 * 256;                    // [B][8] dpre0[:, n0 .. n0 + 7]   (B <= 256)
-  float* xl = wl + 16 * 256;                    // x rows in blocks of XB rows (dW0)
-  const int XB = (256 * MX_WP - 16 * 256) / G;  // rows of x that fit behind d1s / d0s
+  float* rb = wl + 16 * 256;                    // [parts][G][NS] dW0 partial sums (parts * G <= 256)
+  float* xl = wl + 24 * 256;                    // x rows in blocks of XB rows (dW0)
+  const int XB = (256 * MX_WP - 24 * 256) / G;  // rows of x that fit behind d1s / d0s / rb
   // everything this phase reads from memory is requested up front, where the addresses do not depend on anything computed here
   float cpart[8];
   if (blockIdx.x == 0) {                        // classifier: dWc[k] = sum over the workgroups' shares, in workgroup order
@@ -368,8 +397,22 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   };
   ld(0, yv[0]);
   ld(SG4, yv[1]);
-  mx_stage(d1s, B * MX_NS, [&](int e) { return p.dp1[(size_t)(e / MX_NS) * MX_H + n0 + e % MX_NS]; });
-  mx_stage(d0s, B * MX_NS, [&](int e) { return p.dp0[(size_t)(e / MX_NS) * MX_H + n0 + e % MX_NS]; });
+  {                                             // this workgroup's MX_NS feature columns of dpre1 / dpre0: contiguous rows of BP
+    static_assert(MX_NS * BP == 4 * 256, "four elements per thread and array");
+    float v1[4], v0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      v1[u] = p.dp1[(size_t)(n0 + e / BP) * BP + e % BP];
+      v0[u] = p.dp0[(size_t)(n0 + e / BP) * BP + e % BP];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      d1s[(e % BP) * MX_NS + e / BP] = v1[u];   // LDS keeps [row][feature]: the product loops read a row's features together
+      d0s[(e % BP) * MX_NS + e / BP] = v0[u];
+    }
+  }
   const int xb0 = B < XB ? B : XB;
   mx_stage(xl, xb0 * G, [&](int e) { return p.x[e]; });
   __syncthreads();
@@ -403,7 +446,11 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     }
   }
   MX_STAMP(9);
-  {                                              // dW0[n0 + i][g = tid] = sum_b dpre0[b][n0 + i] x[b][g]   (G <= 256)
+  {                                              // dW0[n0 + i][g] = sum_b dpre0[b][n0 + i] x[b][g]   (G <= 256)
+    // all 256 threads: thread = (batch part, input column g), `parts` = 256 / G interleaved row subsets (36 columns alone
+    // would leave 220 threads idle over 128 serial rows); the parts meet in LDS and are added in part order
+    const int parts = 256 / G, part = tid / G, g = tid - part * G;
+    const bool live = part < parts;
     float a[MX_NS];
 #pragma unroll
     for (int i = 0; i < MX_NS; ++i) a[i] = 0.f;
@@ -414,34 +461,46 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
         mx_stage(xl, nb * G, [&](int e) { return p.x[(size_t)bs * G + e]; });
         __syncthreads();
       }
-      if (tid < G) {
+      if (live) {
 #pragma unroll 4
-        for (int b = 0; b < nb; ++b) {
-          const float xv = xl[b * G + tid];
+        for (int b = part; b < nb; b += parts) {
+          const float xv = xl[b * G + g];
           const float* dv = d0s + (bs + b) * MX_NS;
 #pragma unroll
           for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * xv;
         }
       }
     }
-    if (tid < G) {
+    if (live) {
 #pragma unroll
-      for (int i = 0; i < MX_NS; ++i) {
-        float* o = p.dW0 + (size_t)(n0 + i) * G + tid;
-        *o = p.accumulate ? *o + a[i] : a[i];
-      }
+      for (int i = 0; i < MX_NS; ++i) rb[(part * G + g) * MX_NS + i] = a[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < G * MX_NS; e += 256) {   // element (g, i): the parts in order
+      float sum = 0.f;
+      for (int q = 0; q < parts; ++q) sum += rb[q * G * MX_NS + e];
+      const int gg = e / MX_NS, i = e - gg * MX_NS;
+      float* o = p.dW0 + (size_t)(n0 + i) * G + gg;
+      *o = p.accumulate ? *o + sum : sum;
     }
   }
   MX_STAMP(10);
-  if (tid < 2 * MX_NS) {                         // db1 / db0 of the slice
-    const int i = tid % MX_NS;
-    const float* src = tid < MX_NS ? d1s : d0s;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < B; b += 2) { s0 += src[b * MX_NS + i]; s1 += src[(b + 1) * MX_NS + i]; }
-    if (b < B) s0 += src[b * MX_NS + i];
-    float* o = (tid < MX_NS ? p.db1 : p.db0) + n0 + i;
-    *o = p.accumulate ? *o + (s0 + s1) : (s0 + s1);
+  {                                              // db1 / db0 of the slice: 16 lanes per (array, feature), rows interleaved
+    constexpr int NSUM = 2 * MX_NS;              // 16 (or 8) sums
+    const int sidx = tid >> 4, sub = tid & 15;   // 256 threads = 16 sums x 16 lanes
+    float sacc = 0.f;
+    if (sidx < NSUM) {
+      const int i = sidx % MX_NS;
+      const float* src = sidx < MX_NS ? d1s : d0s;
+      for (int b = sub; b < B; b += 16) sacc += src[b * MX_NS + i];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (sidx < NSUM && sub == 0) {
+      const int i = sidx % MX_NS;
+      float* o = (sidx < MX_NS ? p.db1 : p.db0) + n0 + i;
+      *o = p.accumulate ? *o + sacc : sacc;
+    }
   }
   MX_STAMP(11);
   if (blockIdx.x == 0) {
@@ -469,7 +528,11 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
 }
 
-size_t maxnet_step_workspace_floats(int B) { return (size_t)4 * B * MX_H + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW_MAX * MX_H; }
+int maxnet_step_dp_pitch(int B) { return (B <= MX_R * 32 ? 32 : 64) * MX_R; }     // BP of the kernel the launcher picks
+
+size_t maxnet_step_workspace_floats(int B) {
+  return (size_t)2 * B * MX_H + (size_t)2 * MX_H * maxnet_step_dp_pitch(B) + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW_MAX * MX_H;
+}
 
 bool maxnet_step_ok(int B, int G, int H0, int H1) { return B >= 1 && B <= 256 && G >= 1 && G <= 256 && H0 == MX_H && H1 == MX_H; }
 

@@ -112,7 +112,7 @@ struct MaxnetStepParams {
   uint32_t key0, key1;
   const uint32_t* seed_dev;
   float loss_scale;
-  float *y0, *y1, *dp1, *dp0, *dr;   // workspace: [B][256] x 4, [B]
+  float *y0, *y1, *dp1, *dp0, *dr;   // workspace: y0, y1 [B][256]; dp1, dp0 TRANSPOSED [256][maxnet_step_dp_pitch(B)]; dr [B]
   float* dwc_part;                   // workspace: [32 workgroups][256] shares of dWc
   unsigned long long* stamps;        // -DMMF_STAMPS builds: 8 words of wall-clock stamps written by workgroup 0, else null
   unsigned* bar;                     // 3 tick words
@@ -121,6 +121,7 @@ struct MaxnetStepParams {
   int accumulate;
 };
 size_t maxnet_step_workspace_floats(int B);
+int maxnet_step_dp_pitch(int B);
 bool maxnet_step_ok(int B, int G, int H0, int H1);
 int launch_maxnet_cox_step(MaxnetStepParams p, hipStream_t st);
 
