@@ -50,10 +50,14 @@ __device__ inline MxDrop mx_drop(float p) {
 __device__ inline void mx_grid_barrier(unsigned* cnt, int nw) {
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifndef MMF_MX_NOFENCE               // (diagnostic build: the barrier without its fences -- results are wrong, the time is the point)
     __threadfence();                 // release: this workgroup's stores are visible device-wide
+#endif
     __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nw) __builtin_amdgcn_s_sleep(1);
+#ifndef MMF_MX_NOFENCE
     __threadfence();                 // acquire
+#endif
   }
   __syncthreads();
 }
@@ -66,14 +70,36 @@ __device__ inline void mx_grid_barrier(unsigned* cnt, int nw) {
 // same four k of 16 consecutive rows: 16 x 4 distinct banks) conflict-free.  `pre` runs once, right behind the first chunk's
 // load requests: work that does not depend on W hides their latency.
 constexpr int MX_WP = 68;
+// One wave per SIMD: nothing hides an LDS round trip, and the compiler sinks every LDS read next to its use (three reads,
+// a full wait, four MFMAs, 16 times per chunk = 2.6 k of a chunk's 2.9 k cycles).  A batch of reads written in front of this
+// fence is issued before anything behind it (the memory clobber keeps the reads in front, the scheduling barrier keeps the
+// MFMAs, which are not memory operations, behind).
+#define MX_ISSUE_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+typedef float mx_v4f __attribute__((ext_vector_type(4)));
+// v_mfma_f32_4x4x1 with CBSZ = 4: the A values of block ABID (lanes 4 ABID .. 4 ABID + 3) serve all 16 blocks.  A register
+// whose lane l holds A[row l % 4][k0 + l / 4] therefore feeds 16 consecutive k -- one 4-byte LDS read per lane and 16 k
+// instead of one per k.
+#define MX_MFMA_K(acc, areg, bval, q) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(areg, bval, acc, 4, q, 0)
 template <int R, bool VEC, class Pre>
 __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* __restrict__ W, int ldw, int K, float* wl,
-                                    float (&acc)[R], Pre&& pre) {
+                                    float (&acc)[R], Pre&& pre, unsigned long long* dbg = nullptr) {
+#ifdef MMF_STAMPS
+#define MX_GSTAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MX_GSTAMP(i)
+  (void)dbg;
+#endif
   const int tid = threadIdx.x;
+  typedef mx_v4f v4f;
+  // four accumulator sets, k mod 4: a chain of dependent 4x4x1 MFMAs advances one instruction per ~44 cycles (measured: 64 of
+  // them 2.8 k cycles), four interleaved chains keep the unit busy; the sets are added at the end, (0 + 1) + (2 + 3)
+  v4f accq[4];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = 0.f;
-  float4 stage[16];
-  auto fetch = [&](int k0) {
+  for (int q = 0; q < 4; ++q) accq[q] = v4f{0.f, 0.f, 0.f, 0.f};
+  // two chunks travel in registers: with the products on the matrix unit a chunk is multiplied in ~1 k cycles, less than
+  // the round trip of the next one's loads
+  float4 stage0[16], stage1[16];
+  auto fetch = [&](int k0, float4 (&stage)[16]) {
     if constexpr (VEC) {             // thread t: float4 e = t + 256 i of the [256][16 float4] chunk: row e / 16, float4 e % 16
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -89,7 +115,7 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
       }
     }
   };
-  auto put = [&]() {
+  auto put = [&](const float4 (&stage)[16]) {
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -105,40 +131,64 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
       }
     }
   };
-  fetch(0);
-  pre();
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    __syncthreads();                 // the previous chunk has been read by everybody
-    put();
-    __syncthreads();
-    if (k0 + 64 < K) fetch(k0 + 64);
+  // The products run on v_mfma_f32_4x4x1_16B_f32: 16 independent 4 x 4 blocks per instruction -- block q of a wave is the
+  // wave's columns 4 q .. 4 q + 3 against the workgroup's four rows.  Lane l supplies A = x[row l % 4][k] (one 4-byte LDS
+  // read per k) and B = W[column l][k]; its four accumulator registers are rows 0 .. 3 of column l -- the same ownership as
+  // a scalar loop over k, one k per instruction.
+  static_assert(R == 4, "the 4 x 4 x 1 blocks hold four rows");
+  auto chunk = [&](int k0) {
     const int kn = K - k0 < 64 ? K - k0 : 64;
     const float* wr = wl + tid * MX_WP;
-    if (kn == 64) {                  // a full chunk: 16 k at a time, their LDS reads issued together
-#pragma unroll 1
-      for (int kq = 0; kq < 64; kq += 16) {
-        float4 w4[4];
+    const float* xa = xs + (size_t)k0 * R + (tid & 3);
+    if (kn == 64) {                  // a full chunk: all of its LDS reads (16 x 16 B of W, 64 x 4 B of x) in one batch
+      float4 w4[16];
+      float a16[4];                  // lane l: x[row l % 4][k0 + 16 g + l / 4]  (xs is [k][4]: element k0 * 4 + 64 g + l)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w4[u] = ld4(wr + kq + 4 * u);
-        const float w[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
-                             w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+      for (int u = 0; u < 16; ++u) w4[u] = ld4(wr + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const float* xv = xs + (size_t)(k0 + kq + u) * R;
+      for (int g = 0; g < 4; ++g) a16[g] = xs[(size_t)k0 * R + 64 * g + (tid & 63)];
+      MX_ISSUE_FENCE();
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[r] += xv[r] * w[u];
-        }
+      for (int g = 0; g < 4; ++g) {
+#define MX_Q4(j) MX_MFMA_K(accq[0], a16[g], w4[4 * g + j].x, 4 * j); MX_MFMA_K(accq[1], a16[g], w4[4 * g + j].y, 4 * j + 1); \
+                 MX_MFMA_K(accq[2], a16[g], w4[4 * g + j].z, 4 * j + 2); MX_MFMA_K(accq[3], a16[g], w4[4 * g + j].w, 4 * j + 3)
+        MX_Q4(0); MX_Q4(1); MX_Q4(2); MX_Q4(3);
+#undef MX_Q4
       }
     } else {
-#pragma unroll 4
-      for (int kk = 0; kk < kn; ++kk) {
-        const float w = wr[kk];
-        const float* xv = xs + (size_t)(k0 + kk) * R;
+      int kk = 0;
+      for (; kk + 3 < kn; kk += 4) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] += xv[r] * w;
+        for (int u = 0; u < 4; ++u)
+          accq[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(size_t)(kk + u) * R], wr[kk + u], accq[u], 0, 0, 0);
       }
+      for (; kk < kn; ++kk) accq[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[(size_t)kk * R], wr[kk], accq[0], 0, 0, 0);
+    }
+  };
+  fetch(0, stage0);
+  if (K > 64) fetch(64, stage1);
+  pre();
+  MX_GSTAMP(0);
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    __syncthreads();                 // the previous chunk has been read by everybody
+    put(stage0);
+    __syncthreads();
+    if (k0 == 0) MX_GSTAMP(1);
+    if (k0 + 128 < K) fetch(k0 + 128, stage0);
+    chunk(k0);
+    if (k0 == 0) MX_GSTAMP(2);
+    if (k0 + 64 < K) {
+      __syncthreads();
+      put(stage1);
+      __syncthreads();
+      if (k0 + 192 < K) fetch(k0 + 192, stage1);
+      chunk(k0 + 64);
     }
   }
+  MX_GSTAMP(3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (accq[0][r] + accq[1][r]) + (accq[2][r] + accq[3][r]);
 }
 
 // dst[e] = src(e) for e < n, every thread's loads of a batch of 8 issued before its first LDS store (a plain loop is one
@@ -206,7 +256,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     __syncthreads();                            // every thread is done with xs as layer 0's input
 #pragma unroll
     for (int r = 0; r < R; ++r) xs[tid * R + r] = y0d[r];
-  });
+  }, p.stamps ? p.stamps + 12 : nullptr);
   float part[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -330,8 +380,9 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   __syncthreads();
   {
     float a[R];
+    mx_v4f aq[4];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r] = 0.f;
+    for (int q = 0; q < 4; ++q) aq[q] = mx_v4f{0.f, 0.f, 0.f, 0.f};
     // dy0[r][k = tid] = sum_n dpre1[r][n] W1[n][k]: W1 is read as it lies (row n, coalesced along k), 16 rows per stage and the
     // next stage's 16 loads in flight while this one multiplies (the loop is a chain of memory round trips otherwise)
     // (64 rows per stage, two stages requested before the first is used: with 16-row stages every stage waited out a full
@@ -343,18 +394,25 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int nb = nb0 + h * SG;
+        // the same 4 x 4 x 1 blocks as the forward layers: lane = column k, A = dpre1[row l % 4][n] from LDS (the stage's 32
+        // reads in one batch), B = W1[n][k] from the registers the stage travelled in
+        static_assert(SG == 32, "two 16-row groups per stage");
+        float dv16[2];                          // lane l: dpre1[row l % 4][n = nb + 16 g + l / 4]
 #pragma unroll
-        for (int u = 0; u < SG; ++u) {
-          const float* dv = dps + (nb + u) * R;
-#pragma unroll
-          for (int r = 0; r < R; ++r) a[r] += dv[r] * w[h][u];
-        }
+        for (int g = 0; g < 2; ++g) dv16[g] = dps[(nb + 16 * g) * R + (tid & 63)];
+        MX_ISSUE_FENCE();
+#define MX_D4(g, j) MX_MFMA_K(aq[0], dv16[g], w[h][16 * g + 4 * j], 4 * j); MX_MFMA_K(aq[1], dv16[g], w[h][16 * g + 4 * j + 1], 4 * j + 1); \
+                    MX_MFMA_K(aq[2], dv16[g], w[h][16 * g + 4 * j + 2], 4 * j + 2); MX_MFMA_K(aq[3], dv16[g], w[h][16 * g + 4 * j + 3], 4 * j + 3)
+        MX_D4(0, 0); MX_D4(0, 1); MX_D4(0, 2); MX_D4(0, 3); MX_D4(1, 0); MX_D4(1, 1); MX_D4(1, 2); MX_D4(1, 3);
+#undef MX_D4
         if (nb + 2 * SG < MX_H) {
 #pragma unroll
           for (int u = 0; u < SG; ++u) w[h][u] = p.W1[(size_t)(nb + 2 * SG + u) * MX_H + tid];
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = (aq[0][r] + aq[1][r]) + (aq[2][r] + aq[3][r]);
     float d0[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -419,25 +477,45 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   MX_STAMP(8);
   {
     float a[MX_NS];
-#pragma unroll
-    for (int i = 0; i < MX_NS; ++i) a[i] = 0.f;
-    // dW1[n0 + i][k = tid] = sum_b dpre1[b][n0 + i] y0[b][k]: 16 batch rows per stage, the next stage in flight
+    // dW1[n0 + i][k = tid] = sum_b dpre1[b][n0 + i] y0[b][k]: 32 batch rows per stage, the next stage in flight.  4 x 4 x 1
+    // blocks again: lane = column k, A = dpre1[b][feature l % 4 (+ 4)] from LDS (a stage's reads in one batch), B = y0[b][k]
+    // from the stage's registers; two accumulator sets per half of the features (rows alternate)
     constexpr int SG = SG4;
+    constexpr int NH = MX_NS / 4;                // feature quads of this workgroup: 2 (32 workgroups) or 1 (64)
+    mx_v4f dq[NH][2];
+#pragma unroll
+    for (int f = 0; f < NH; ++f) { dq[f][0] = mx_v4f{0.f, 0.f, 0.f, 0.f}; dq[f][1] = mx_v4f{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 1
     for (int b0 = 0; b0 < B; b0 += 2 * SG) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int bb = b0 + SG * h;
         if (bb < B) {
+          static_assert(SG == 32, "two 16-row groups per stage");
+          float dv16[NH][2];                     // lane l: dpre1[b = bb + 16 g + l / 4][feature 4 f + l % 4]
 #pragma unroll
-          for (int u = 0; u < SG; ++u) {
-            const float* dv = d1s + (bb + u < B ? bb + u : 0) * MX_NS;      // rows beyond the batch: yv = 0
+          for (int g = 0; g < 2; ++g) {
+            const int b = bb + 16 * g + ((tid & 63) >> 2);
+            const float* src = d1s + (b < B ? b : 0) * MX_NS + (tid & 3);                 // rows beyond the batch: yv = 0
 #pragma unroll
-            for (int i = 0; i < MX_NS; ++i) a[i] += dv[i] * yv[h][u];
+            for (int f = 0; f < NH; ++f) dv16[f][g] = src[4 * f];
+          }
+          MX_ISSUE_FENCE();
+#pragma unroll
+          for (int f = 0; f < NH; ++f) {
+#define MX_W4(g, j) MX_MFMA_K(dq[f][0], dv16[f][g], yv[h][16 * g + 4 * j], 4 * j); MX_MFMA_K(dq[f][1], dv16[f][g], yv[h][16 * g + 4 * j + 1], 4 * j + 1); \
+                    MX_MFMA_K(dq[f][0], dv16[f][g], yv[h][16 * g + 4 * j + 2], 4 * j + 2); MX_MFMA_K(dq[f][1], dv16[f][g], yv[h][16 * g + 4 * j + 3], 4 * j + 3)
+            MX_W4(0, 0); MX_W4(0, 1); MX_W4(0, 2); MX_W4(0, 3); MX_W4(1, 0); MX_W4(1, 1); MX_W4(1, 2); MX_W4(1, 3);
+#undef MX_W4
           }
           if (bb + 2 * SG < B) ld(bb + 2 * SG, yv[h]);
         }
       }
+    }
+#pragma unroll
+    for (int f = 0; f < NH; ++f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[4 * f + i] = dq[f][0][i] + dq[f][1][i];
     }
 #pragma unroll
     for (int i = 0; i < MX_NS; ++i) {

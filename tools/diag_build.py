@@ -39,6 +39,7 @@ VARIANTS = {"f2cond": ["-DMMF_F2_COND_LOAD"], "f2cond_slp": ["-DMMF_F2_COND_LOAD
             "tune": ["-DMMF_TUNE"],      # the product kernels + the MMF_* environment overrides of the launch plans (tools/README.md)
             "noload": ["-DMMF_DIAG_NOLOAD"], "nomfma": ["-DMMF_DIAG_NOMFMA"],
             "stamps": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT"],
+            "mxnofence": ["-DMMF_STAMPS", "-DMMF_STAMPS_LIGHT", "-DMMF_MX_NOFENCE"],   # omic step: what the barriers' fences cost (WRONG results)
             "f2noact": ["-DMMF_F2_GATE_NOACT"], "f2nown": ["-DMMF_F2_GATE_NOWN"], "f2nomm": ["-DMMF_F2_GATE_NOMM"],
             "f2prio0": ["-DMMF_F2_PRIO=0"], "f2prio3": ["-DMMF_F2_PRIO=3"],
             "gprio0": ["-DMMF_GEMM_PRIO=0"],

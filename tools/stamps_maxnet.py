@@ -28,4 +28,6 @@ for it in range(5):
     st = ws[off:off + 128].view(torch.int64).cpu().numpy()
     names = ["L0 gemm", "L1 + classifier", "barrier 1", "Cox", "phase 3", "barrier 2", "phase 4"]
     print("  ".join(f"{n} {int(st[i + 1] - st[i])}" for i, n in enumerate(names)), " total cycles", int(st[7] - st[0]),
-          "| phase 4: staging", int(st[8] - st[6]), "dW1", int(st[9] - st[8]), "dW0", int(st[10] - st[9]), "db", int(st[11] - st[10]), "dWc/dbc", int(st[7] - st[11]))
+          "| phase 4: staging", int(st[8] - st[6]), "dW1", int(st[9] - st[8]), "dW0", int(st[10] - st[9]), "db", int(st[11] - st[10]), "dWc/dbc", int(st[7] - st[11]),
+          "| layer 1 from phase start: loads issued + pre", int(st[12] - st[1]), "first chunk in LDS", int(st[13] - st[12]), "chunk 0 multiplied", int(st[14] - st[13]),
+          "chunks 1-3", int(st[15] - st[14]), "epilogue + classifier", int(st[2] - st[15]))
