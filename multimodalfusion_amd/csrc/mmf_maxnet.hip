@@ -107,6 +107,9 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
         stage[i] = ld4(W + (size_t)(e >> 4) * ldw + k0 + 4 * (e & 15));
       }
     } else {                         // any ldw / K: scalars, element e = t + 256 i: row e / 64, column e % 64
+      // (tried for layer 0, G = 36, 9.4 k cycles: only the chunk's 36 columns with row / column advanced incrementally -- 13 k,
+      // the address chain serialises the loads; W0 as one contiguous block of 16-byte loads with a division per float4 --
+      // 8.6 k, but 36 - 44 B of scratch per lane from the second staging path; neither kept)
       float* sf = reinterpret_cast<float*>(stage);
 #pragma unroll
       for (int i = 0; i < 64; ++i) {
