@@ -162,3 +162,52 @@ def test_surv_head_nll_step_shapes():
         np.testing.assert_allclose(out[5].cpu().numpy(), f64.grad.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(dWk.cpu().numpy(), W64.grad.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(dbk.cpu().numpy(), b64.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["mm_concat", "mm_tensor", "radio"])
+@pytest.mark.parametrize("flat", [False, True])
+def test_loop_takes_the_one_call_step_and_matches_the_autograd_route(which, flat):
+    """utils/core_utils.train_loop_survival (gc = 2, four patients, eval-mode masks off) with the one-call step against the
+    same loop with `model.mmf_one_call_step = False` (model(**feats) + loss + backward through autograd): same losses, same
+    parameters after the two optimizer steps, with torch.optim.Adam + autograd L1 and with FlatAdam (fused L1 + Adam tail)."""
+    from multimodalfusion_amd.models import MIL_Attention_fc_surv_radio, MM_MIL_Attention_fc_surv
+    from multimodalfusion_amd.optim import FlatAdam
+    from multimodalfusion_amd.utils import core_utils
+    from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
+    from multimodalfusion_amd.utils.utils import l1_reg_all
+    rng = np.random.default_rng(3)
+    loader = []
+    for i in range(4):
+        radio = {m: torch.as_tensor(rng.standard_normal((40 + 8 * i, 1024)).astype(np.float32)) for m in cases.MODS}
+        path = torch.as_tensor(rng.standard_normal((300 + 50 * i, 1024)).astype(np.float32))
+        omic = torch.as_tensor(rng.standard_normal((1, 80)).astype(np.float32))
+        loader.append((radio, path, omic, torch.tensor([i % 4]), np.array([10.0 + i]), torch.tensor([float(i % 2)])))
+    outs = []
+    for one_call in (True, False):
+        torch.manual_seed(11)
+        if which == "radio":
+            model, mode = MIL_Attention_fc_surv_radio(n_classes=4, dropout=False), "radio"
+        else:
+            model, mode = MM_MIL_Attention_fc_surv(input_dim=80, fusion=which[3:], n_classes=4), "radio_path_omic"
+        model = model.to(DEV)
+        model.eval()
+        model.train = lambda mode=True, _m=model: _m          # dropout off: the two routes draw their seeds alike anyway
+        model.mmf_one_call_step = one_call
+        called = []
+        orig = model.nll_step
+        model.nll_step = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+        if flat:
+            opt = FlatAdam(model, lr=1e-3, weight_decay=1e-4, lambda_l1=1e-5)
+        else:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        out = core_utils.train_loop_survival(0, model, loader, opt, 4, mode, loss_fn=NLLSurvLoss(alpha=0.1), reg_fn=l1_reg_all,
+                                             lambda_reg=1e-5, gc=2)
+        assert bool(called) == one_call
+        outs.append((out["losses"].copy(), {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)
+    for k, v in outs[0][1].items():
+        ref = outs[1][1][k]
+        # Adam divides by sqrt(v): an element whose gradient is a near-cancellation moves by lr * O(relative gradient error),
+        # so the bar is a few percent of one normalised step (lr = 1e-3); gradient-level equality is tested above
+        d = float((v - ref).abs().max())
+        assert d <= 5e-5 + 2e-5 * float(ref.abs().max()), (k, d)
