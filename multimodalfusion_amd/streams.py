@@ -44,6 +44,10 @@ def stream_beside(others, device=None, tries: int = 12) -> torch.cuda.Stream:
     last = None
     for _ in range(tries):
         last = torch.cuda.Stream(device)
-        if all(_runs_beside(o, last, device) for o in others):
+        try:
+            if all(_runs_beside(o, last, device) for o in others):
+                return last
+        except torch.cuda.OutOfMemoryError:  # no room for the probe's operand: an unmeasured stream is still a correct one
+            torch.cuda.synchronize(device)
             return last
     return last                              # nothing passed (one hardware queue?): still correct, just not concurrent
