@@ -194,6 +194,50 @@ __device__ inline void mx_rows_gemm(const float* __restrict__ xs, const float* _
   for (int r = 0; r < 4; ++r) acc[r] = (accq[0][r] + accq[1][r]) + (accq[2][r] + accq[3][r]);
 }
 
+// The same product for a narrow first layer (K <= 64, K % 4 == 0, W = one contiguous 16-byte aligned [256][K] block: G = 36):
+// thread n keeps ITS row of W in registers -- K / 4 16-byte loads per lane, 144 bytes apart at K = 36, so a wave's K / 4
+// instructions together read one contiguous 9 KB block -- and nothing goes through LDS but x.  (The chunked path stages a
+// 64-wide chunk of a 36-wide matrix with 64 predicated scalar loads and LDS stores per thread: 9.4 k cycles.)
+template <int R, class Pre>
+__device__ inline void mx_rows_narrow(const float* __restrict__ xs, const float* __restrict__ W, int K, float (&acc)[R], Pre&& pre) {
+  static_assert(R == 4, "the 4 x 4 x 1 blocks hold four rows");
+  const int tid = threadIdx.x;
+  float4 w4[16];
+  const float* wrow = W + (size_t)tid * K;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (4 * i < K) w4[i] = ld4(wrow + 4 * i);
+  pre();
+  __syncthreads();                   // x is in LDS
+  mx_v4f accq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) accq[q] = mx_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (16 * g + 15 < K) {           // a full group of 16 k on one broadcast A register
+      const float a16 = xs[64 * g + (tid & 63)];
+#define MX_Q4(j) MX_MFMA_K(accq[0], a16, w4[4 * g + j].x, 4 * j); MX_MFMA_K(accq[1], a16, w4[4 * g + j].y, 4 * j + 1); \
+                 MX_MFMA_K(accq[2], a16, w4[4 * g + j].z, 4 * j + 2); MX_MFMA_K(accq[3], a16, w4[4 * g + j].w, 4 * j + 3)
+      MX_Q4(0); MX_Q4(1); MX_Q4(2); MX_Q4(3);
+#undef MX_Q4
+    } else {                         // the last, partial group: four k per 16-byte register
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * g + 4 * j;
+        if (k < K) {
+          const float* xa = xs + (size_t)k * R + (tid & 3);
+          accq[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[0], w4[4 * g + j].x, accq[0], 0, 0, 0);
+          accq[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[R], w4[4 * g + j].y, accq[1], 0, 0, 0);
+          accq[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[2 * R], w4[4 * g + j].z, accq[2], 0, 0, 0);
+          accq[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[3 * R], w4[4 * g + j].w, accq[3], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (accq[0][r] + accq[1][r]) + (accq[2][r] + accq[3][r]);
+}
+
 // dst[e] = src(e) for e < n, every thread's loads of a batch of 8 issued before its first LDS store (a plain loop is one
 // memory round trip per element: the compiler keeps a load in front of the store that might alias it)
 template <class Src>
@@ -237,12 +281,14 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
 
   // ---------------- phase 1: this workgroup's rows through the net ----------------------------------------------------
   float acc[R], y0d[R], y1d[R];
-  mx_rows_gemm<R, false>(xs, p.W0, G, G, wl, acc, [&]() {
+  auto stage_x = [&]() {
     for (int e = tid; e < G * R; e += 256) {    // the rows' inputs, behind W0's load requests
       const int k = e / R, r = e % R;
       xs[e] = (r0 + r < B) ? p.x[(size_t)(r0 + r) * G + k] : 0.f;
     }
-  });
+  };
+  if (G <= 64 && (G & 3) == 0 && (reinterpret_cast<uintptr_t>(p.W0) & 15) == 0) mx_rows_narrow<R>(xs, p.W0, G, acc, stage_x);
+  else mx_rows_gemm<R, false>(xs, p.W0, G, G, wl, acc, stage_x);
   MX_STAMP(1);
   {
     const float b = p.b0[tid];
