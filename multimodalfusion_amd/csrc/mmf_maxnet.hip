@@ -47,16 +47,21 @@ __device__ inline MxDrop mx_drop(float p) {
   return d;
 }
 
+// FENCED = false: nothing but values written with device-scope stores and read with device-scope loads crosses this barrier
+// (the risks at barrier 1), so the release / acquire fences -- an L2 write-back and an invalidate -- are left out: the
+// __syncthreads in front has waited for the stores (workgroup-scope release = vmcnt(0); a device-scope store is complete when
+// it is visible at the coherent level), the ticket is an agent-scope atomic.
+template <bool FENCED = true>
 __device__ inline void mx_grid_barrier(unsigned* cnt, int nw) {
   __syncthreads();
   if (threadIdx.x == 0) {
 #ifndef MMF_MX_NOFENCE               // (diagnostic build: the barrier without its fences -- results are wrong, the time is the point)
-    __threadfence();                 // release: this workgroup's stores are visible device-wide
+    if (FENCED) __threadfence();     // release: this workgroup's stores are visible device-wide
 #endif
     __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nw) __builtin_amdgcn_s_sleep(1);
 #ifndef MMF_MX_NOFENCE
-    __threadfence();                 // acquire
+    if (FENCED) __threadfence();     // acquire
 #endif
   }
   __syncthreads();
@@ -76,6 +81,10 @@ constexpr int MX_WP = 68;
 // MFMAs, which are not memory operations, behind).
 #define MX_ISSUE_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 typedef float mx_v4f __attribute__((ext_vector_type(4)));
+// The risks, all that crosses barrier 1, are written and read at DEVICE scope (the sc1 bit: through to / from the level the
+// XCDs' L2s are coherent at), so that barrier needs no L2 write-back / invalidate around its ticket.
+__device__ inline void mx_st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float mx_ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // v_mfma_f32_4x4x1 with CBSZ = 4: the A values of block ABID (lanes 4 ABID .. 4 ABID + 3) serve all 16 blocks.  A register
 // whose lane l holds A[row l % 4][k0 + l / 4] therefore feeds 16 consecutive k -- one 4-byte LDS read per lane and 16 k
 // instead of one per k.
@@ -312,7 +321,6 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     const float y = mx_selu(acc[r] + b1v);
     const uint32_t idx = (uint32_t)(r0 + r) * MX_H + (uint32_t)tid;
     y1d[r] = dr.on ? dr.a * (keep(key1, idx, dr.thr) ? y : dr.alpha_p) + dr.b : y;
-    if (r0 + r < B) p.y1[(size_t)(r0 + r) * MX_H + tid] = y1d[r];
     part[r] = wave_sum(y1d[r] * wcv);
   }
   __syncthreads();
@@ -321,9 +329,10 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     for (int r = 0; r < R; ++r) red[wave * R + r] = part[r];
   }
   __syncthreads();
-  if (tid < R && r0 + tid < B) p.risk[r0 + tid] = red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + bcv;
+  if (tid < R && r0 + tid < B)       // device-scope store: every workgroup reads every risk right behind barrier 1
+    mx_st_dev(p.risk + r0 + tid, red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + bcv);
   MX_STAMP(2);
-  mx_grid_barrier(p.bar, MX_NW);
+  mx_grid_barrier<false>(p.bar, MX_NW);
   MX_STAMP(3);
 
   // ---------------- phase 2: Cox over the whole batch, gradient of this workgroup's rows ---------------------------------
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   float* lp = wl + 1024;                        // [4] loss terms per wave
   double* tl = reinterpret_cast<double*>(wl + 1280);    // [256] event times
   if (tid < B) {
-    const float t = p.risk[tid];
+    const float t = mx_ld_dev(p.risk + tid);
     th[tid] = t; et[tid] = expf(t); uc[tid] = 1.f - c_pre; tl[tid] = t_pre;
   }
   __syncthreads();
@@ -477,6 +486,8 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     st4(p.dp0 + (size_t)tid * BP + r0, float4{d0[0], d0[1], d0[2], d0[3]});
   }
   MX_STAMP(5);
+  // (tried: y0, dpre1, dpre0, dr and the dWc shares at device scope and this barrier without its fences too -- 32.3 -> 34.3 us:
+  // eight write-through scalar stores per thread instead of two 16-byte ones cost phase 3 more than the fences cost here)
   mx_grid_barrier(p.bar + 1, MX_NW);
   MX_STAMP(6);
 
