@@ -497,15 +497,13 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   float* d0s = wl + 8 * 256;                    // [B][8] dpre0[:, n0 .. n0 + 7]   (B <= 256)
   float* rb = wl + 16 * 256;                    // [parts][G][NS] dW0 partial sums (parts * G <= 256)
   float* xl = wl + 24 * 256;                    // x rows in blocks of XB rows (dW0)
-  const int XB = (256 * MX_WP - 24 * 256) / G;  // rows of x that fit behind d1s / d0s / rb
+  float* cw = wl + 256 * MX_WP - 256;           // [NS][NW] the dWc shares of this workgroup's columns
+  const int XB = (256 * MX_WP - 24 * 256 - 256) / G;   // rows of x that fit behind d1s / d0s / rb and in front of cw
   // everything this phase reads from memory is requested up front, where the addresses do not depend on anything computed here
-  float cpart[8];
-  if (blockIdx.x == 0) {                        // classifier: dWc[k] = sum over the workgroups' shares, in workgroup order
-#pragma unroll
-    for (int u = 0; u < 8; ++u) cpart[u] = 0.f;
-#pragma unroll
-    for (int j = 0; j < MX_NW; ++j) cpart[j & 7] += p.dwc_part[(size_t)j * MX_H + tid];
-  }
+  // classifier: dWc[k] = sum over the workgroups' shares, in workgroup order -- every workgroup does ITS columns (one load per
+  // thread: share tid / NS of column n0 + tid % NS) instead of workgroup 0 all 256 with 32 loads per thread
+  static_assert(MX_NS * MX_NW == 256, "one share element per thread");
+  const float cshare = p.dwc_part[(size_t)(tid / MX_NS) * MX_H + n0 + tid % MX_NS];
   // (the first two stages of dW1's y0 rows are requested here too: one round trip for all of it)
   constexpr int SG4 = 32;
   float yv[2][SG4];
@@ -533,6 +531,7 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
   const int xb0 = B < XB ? B : XB;
   mx_stage(xl, xb0 * G, [&](int e) { return p.x[e]; });
+  cw[(tid % MX_NS) * MX_NW + tid / MX_NS] = cshare;
   __syncthreads();
   MX_STAMP(8);
   {
@@ -585,6 +584,8 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
   MX_STAMP(9);
   {                                              // dW0[n0 + i][g] = sum_b dpre0[b][n0 + i] x[b][g]   (G <= 256)
+    // (tried: the same 4 x 4 x 1 blocks as dW1, lane = column, the waves splitting the batch and meeting in LDS -- 4.8 -> 5.5 k
+    // cycles at G = 36: two 16-row groups per wave do not pay for the extra reduction)
     // all 256 threads: thread = (batch part, input column g), `parts` = 256 / G interleaved row subsets (36 columns alone
     // would leave 220 threads idle over 128 serial rows); the parts meet in LDS and are added in part order
     const int parts = 256 / G, part = tid / G, g = tid - part * G;
@@ -641,9 +642,17 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
     }
   }
   MX_STAMP(11);
-  if (blockIdx.x == 0) {
+  if (tid < MX_NS) {                            // the shares of column n0 + tid in workgroup order, eight interleaved partial sums
+    float cpart[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cpart[u] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MX_NW; ++j) cpart[j & 7] += cw[tid * MX_NW + j];
     const float s = ((cpart[0] + cpart[1]) + (cpart[2] + cpart[3])) + ((cpart[4] + cpart[5]) + (cpart[6] + cpart[7]));
-    p.dWc[tid] = p.accumulate ? p.dWc[tid] + s : s;
+    float* o = p.dWc + n0 + tid;
+    *o = p.accumulate ? *o + s : s;
+  }
+  if (blockIdx.x == 0) {
     float sb = tid < B ? p.dr[tid] : 0.f;       // dbc = sum_b dr[b]
     sb = wave_sum(sb);
     if (lane == 0) red[8 + wave] = sb;
