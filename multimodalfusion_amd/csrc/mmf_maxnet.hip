@@ -675,7 +675,15 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   }
 }
 
-int maxnet_step_dp_pitch(int B) { return (B <= MX_R * 32 ? 32 : 64) * MX_R; }     // BP of the kernel the launcher picks
+// Workgroups of the launch: B / 4 rounded up to 32 or 64 (four rows each).  Measured: 64 workgroups at B = 128 -- phase 4, a
+// third of the step, divides the 256 output features among however many there are, and the 32 workgroups without a batch row
+// run phases 1 - 3 on zero rows beside the others -- 32.0 -> 34.4-35.3 us: twice the arrivals at both barriers and twice the
+// workgroups streaming W1 cost more than half a phase 4 saves (MMF_MX_NW_MIN = 64 in the tuning build).
+static int maxnet_step_workgroups(int B) {
+  static const int nw_min = tune_int("MMF_MX_NW_MIN", 32);
+  return (B > MX_R * 32 || nw_min > 32) ? 64 : 32;
+}
+int maxnet_step_dp_pitch(int B) { return maxnet_step_workgroups(B) * MX_R; }     // BP of the kernel the launcher picks
 
 size_t maxnet_step_workspace_floats(int B) {
   return (size_t)2 * B * MX_H + (size_t)2 * MX_H * maxnet_step_dp_pitch(B) + (size_t)((B + 63) / 64 * 64) + 32 + (size_t)MX_NW_MAX * MX_H;
@@ -684,7 +692,7 @@ size_t maxnet_step_workspace_floats(int B) {
 bool maxnet_step_ok(int B, int G, int H0, int H1) { return B >= 1 && B <= 256 && G >= 1 && G <= 256 && H0 == MX_H && H1 == MX_H; }
 
 int launch_maxnet_cox_step(MaxnetStepParams p, hipStream_t st) {
-  const int nw = p.B <= MX_R * 32 ? 32 : 64;       // four batch rows per workgroup
+  const int nw = maxnet_step_workgroups(p.B);
   const int lds = (256 * MX_R + 256 * MX_WP + 64) * (int)sizeof(float);
   auto kern = nw == 32 ? maxnet_cox_step_kernel<32> : maxnet_cox_step_kernel<64>;
   if (int e = set_dyn_lds(reinterpret_cast<const void*>(kern), lds)) return e;
