@@ -23,14 +23,49 @@ from test_gpu_path import DEV, _grads, _load, _t, compare, relu_kink_units
 pytestmark = pytest.mark.gpu
 
 
+def _config4(fusion):
+    return dict(fusion=fusion, mode="radio_path_omic", Np=50_000, nr=512, G=80, gate_path=True, gate_radio=True, K=4,
+                seed=404, x_seed=405, y=1, c=0, alpha=0.0, bias_std=0.02)
+
+
+_config4_ref = {}
+
+
+def _config4_oracle(fusion):
+    """The fp64 oracle of config 4 and the ReLU-kink allowance, computed once per fusion (10-40 s of CPU each)."""
+    if fusion not in _config4_ref:
+        m = _config4(fusion)
+        sd, xs, xp, xo = cases.mm_inputs(m)
+        _config4_ref[fusion] = (cases.run_mm(m), relu_kink_units(sd, xp))
+    return _config4_ref[fusion]
+
+
 @pytest.mark.parametrize("fusion", ["concat", "tensor"])
 def test_config4_mm_with_50k_fp32_path_bag_vs_fp64_oracle(fusion):
-    m = dict(fusion=fusion, mode="radio_path_omic", Np=50_000, nr=512, G=80, gate_path=True, gate_radio=True, K=4,
-             seed=404, x_seed=405, y=1, c=0, alpha=0.0, bias_std=0.02)
-    res = run_mm_hip(m)
-    ref = cases.run_mm(m)
+    res = run_mm_hip(_config4(fusion))
+    ref, kink = _config4_oracle(fusion)
+    compare(res, ref, f"config4 {fusion}", kink_units=kink)
+
+
+@pytest.mark.parametrize("fusion", ["concat", "tensor"])
+def test_config4_mm_one_call_step_50k_vs_fp64_oracle(fusion):
+    """The same configuration through the step the loop mirror runs (MM_MIL_Attention_fc_surv.nll_step: branch calls by hand on
+    two streams, head + loss + backward in one launch), against the same oracle."""
+    from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
+    m = _config4(fusion)
     sd, xs, xp, xo = cases.mm_inputs(m)
-    compare(res, ref, f"config4 {fusion}", kink_units=relu_kink_units(sd, xp))
+    model = _load(MM_MIL_Attention_fc_surv(input_dim=80, radio_fusion="concat", fusion=fusion, gate=True, gate_path=True,
+                                           gate_omic=True, gate_radio=True, n_classes=4, mode=m["mode"]), sd).eval()
+    kw = {k: _t(x) for k, x in zip(cases.MODS, xs)}
+    kw["path_features"] = _t(xp)
+    kw["genomic_features"] = _t(xo)
+    hz, S, Yh, A_raw, loss, risk = model.nll_step(torch.tensor([m["y"]], device=DEV), torch.tensor([float(m["c"])], device=DEV),
+                                                  alpha=m["alpha"], **kw)
+    torch.cuda.synchronize()
+    res = dict(hazards=hz.cpu().numpy(), S=S.cpu().numpy(), Y_hat=Yh.cpu().numpy(),
+               A_raw={k: v.cpu().numpy() for k, v in A_raw.items()}, loss=float(loss), M=None, grads=_grads(model))
+    ref, kink = _config4_oracle(fusion)
+    compare(res, ref, f"config4 one-call {fusion}", kink_units=kink)
 
 
 def test_config5_bf16_path_head_100k_vs_bf16_oracle(monkeypatch):
