@@ -79,8 +79,14 @@ def test_config5_bf16_path_head_100k_vs_bf16_oracle(monkeypatch):
     compare_bf16(res, ref, "config5 path 100k", a_tol=5e-3, h_tol=2e-3, l_tol=1e-3, g_rel=1e-2)
 
 
+_config5_ref = {}
+
+
+@pytest.mark.parametrize("route", ["autograd", "one_call"])
 @pytest.mark.parametrize("fusion", ["concat", "tensor"])
-def test_config5_mm_with_100k_bf16_path_bag_vs_bf16_oracle(fusion):
+def test_config5_mm_with_100k_bf16_path_bag_vs_bf16_oracle(fusion, route):
+    """route: model(**kw) + loss + backward through autograd, or the step the loop mirror runs (nll_step); one oracle run per
+    fusion serves both."""
     from multimodalfusion_amd.models import MM_MIL_Attention_fc_surv
     from multimodalfusion_amd.utils.loss_utils import NLLSurvLoss
     m = dict(fusion=fusion, mode="radio_path_omic", Np=100_000, nr=512, G=80, gate_path=True, gate_radio=True, K=4,
@@ -93,14 +99,20 @@ def test_config5_mm_with_100k_bf16_path_bag_vs_bf16_oracle(fusion):
     kw = {k: _t(x) for k, x in zip(cases.MODS, xs)}
     kw["path_features"] = torch.as_tensor(xq).to(torch.float32).to(torch.bfloat16).to(DEV)
     kw["genomic_features"] = _t(xo)
-    hz, S, Yh, A_raw = model(**kw)
-    loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([m["y"]], device=DEV), c=torch.tensor([0.0], device=DEV))
-    loss.backward()
+    if route == "autograd":
+        hz, S, Yh, A_raw = model(**kw)
+        loss = NLLSurvLoss(alpha=0.0)(hazards=hz, S=S, Y=torch.tensor([m["y"]], device=DEV), c=torch.tensor([0.0], device=DEV))
+        loss.backward()
+    else:
+        hz, S, Yh, A_raw, loss, _ = model.nll_step(torch.tensor([m["y"]], device=DEV), torch.tensor([0.0], device=DEV), alpha=0.0, **kw)
+        torch.cuda.synchronize()
     res = dict(hazards=hz.detach().cpu().numpy(), loss=float(loss.detach()), grads=_grads(model),
                A={k: v.detach().cpu().numpy() for k, v in A_raw.items()})
-    ref = bf16_port.mm_step_bf16(sd, xs, xq, xo, m["y"], m["c"], m["alpha"], fusion=fusion, gate_path=True,
-                                 gate_radio=True, mode=m["mode"])
-    tag = f"config5 mm {fusion}"
+    if fusion not in _config5_ref:
+        _config5_ref[fusion] = bf16_port.mm_step_bf16(sd, xs, xq, xo, m["y"], m["c"], m["alpha"], fusion=fusion, gate_path=True,
+                                                      gate_radio=True, mode=m["mode"])
+    ref = _config5_ref[fusion]
+    tag = f"config5 mm {fusion} {route}"
     assert abs(res["loss"] - ref["loss"]) <= 1e-3, (tag, res["loss"], ref["loss"])
     np.testing.assert_allclose(res["hazards"], ref["hazards"], rtol=0, atol=2e-3, err_msg=tag)
     # the radiology branch never sees bf16: the fp32 bar
