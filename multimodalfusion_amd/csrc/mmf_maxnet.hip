@@ -51,9 +51,12 @@ __device__ inline MxDrop mx_drop(float p) {
 // (the risks at barrier 1), so the release / acquire fences -- an L2 write-back and an invalidate -- are left out: the
 // __syncthreads in front has waited for the stores (workgroup-scope release = vmcnt(0); a device-scope store is complete when
 // it is visible at the coherent level), the ticket is an agent-scope atomic.
-template <bool FENCED = true>
-__device__ inline void mx_grid_barrier(unsigned* cnt, int nw) {
+// `mid` runs on every thread between the two workgroup barriers, i.e. while thread 0 takes its ticket and polls: loads that
+// depend on nothing another workgroup writes are requested there and travel during the wait.
+template <bool FENCED = true, class Mid>
+__device__ inline void mx_grid_barrier(unsigned* cnt, int nw, Mid&& mid) {
   __syncthreads();
+  mid();
   if (threadIdx.x == 0) {
 #ifndef MMF_MX_NOFENCE               // (diagnostic build: the barrier without its fences -- results are wrong, the time is the point)
     if (FENCED) __threadfence();     // release: this workgroup's stores are visible device-wide
@@ -332,7 +335,14 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   if (tid < R && r0 + tid < B)       // device-scope store: every workgroup reads every risk right behind barrier 1
     mx_st_dev(p.risk + r0 + tid, red[tid] + red[R + tid] + red[2 * R + tid] + red[3 * R + tid] + bcv);
   MX_STAMP(2);
-  mx_grid_barrier<false>(p.bar, MX_NW);
+  constexpr int SG3 = 32;
+  float w3[2][SG3];                             // dy0's first two stages of W1 rows (phase 3), requested while the barrier waits
+  mx_grid_barrier<false>(p.bar, MX_NW, [&]() {
+#pragma unroll
+    for (int u = 0; u < SG3; ++u) w3[0][u] = p.W1[(size_t)u * MX_H + tid];
+#pragma unroll
+    for (int u = 0; u < SG3; ++u) w3[1][u] = p.W1[(size_t)(SG3 + u) * MX_H + tid];
+  });
   MX_STAMP(3);
 
   // ---------------- phase 2: Cox over the whole batch, gradient of this workgroup's rows ---------------------------------
@@ -406,12 +416,6 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   MX_STAMP(4);
   // ---------------- phase 3: d pre-activations of this workgroup's rows --------------------------------------------------
   float* dps = xs;                              // [256][R] dpre1 of these rows (layer 1's outputs n)
-  constexpr int SG3 = 32;
-  float w3[2][SG3];                             // dy0's first two stages of W1 rows, requested before anything else
-#pragma unroll
-  for (int u = 0; u < SG3; ++u) w3[0][u] = p.W1[(size_t)u * MX_H + tid];
-#pragma unroll
-  for (int u = 0; u < SG3; ++u) w3[1][u] = p.W1[(size_t)(SG3 + u) * MX_H + tid];
   {
     float wpart = 0.f;                          // this workgroup's share of dWc[k = tid] = sum_b dr[b] y1[b][k]
     float dd[R];
@@ -488,17 +492,20 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
   MX_STAMP(5);
   // (tried: y0, dpre1, dpre0, dr and the dWc shares at device scope and this barrier without its fences too -- 32.3 -> 34.3 us:
   // eight write-through scalar stores per thread instead of two 16-byte ones cost phase 3 more than the fences cost here)
-  mx_grid_barrier(p.bar + 1, MX_NW);
-  MX_STAMP(6);
-
-  // ---------------- phase 4: weight gradients, 8 output features per workgroup ------------------------------------------
-  const int n0 = blockIdx.x * MX_NS;
+  // phase 4's LDS map (wl is free from here on); the first block of x rows -- an input, nothing another workgroup writes --
+  // is staged while the barrier waits
   float* d1s = wl;                              // [B][8] dpre1[:, n0 .. n0 + 7]
   float* d0s = wl + 8 * 256;                    // [B][8] dpre0[:, n0 .. n0 + 7]   (B <= 256)
   float* rb = wl + 16 * 256;                    // [parts][G][NS] dW0 partial sums (parts * G <= 256)
   float* xl = wl + 24 * 256;                    // x rows in blocks of XB rows (dW0)
   float* cw = wl + 256 * MX_WP - 256;           // [NS][NW] the dWc shares of this workgroup's columns
   const int XB = (256 * MX_WP - 24 * 256 - 256) / G;   // rows of x that fit behind d1s / d0s / rb and in front of cw
+  const int xb0 = B < XB ? B : XB;
+  mx_grid_barrier(p.bar + 1, MX_NW, [&]() { mx_stage(xl, xb0 * G, [&](int e) { return p.x[e]; }); });
+  MX_STAMP(6);
+
+  // ---------------- phase 4: weight gradients, 8 output features per workgroup ------------------------------------------
+  const int n0 = blockIdx.x * MX_NS;
   // everything this phase reads from memory is requested up front, where the addresses do not depend on anything computed here
   // classifier: dWc[k] = sum over the workgroups' shares, in workgroup order -- every workgroup does ITS columns (one load per
   // thread: share tid / NS of column n0 + tid % NS) instead of workgroup 0 all 256 with 32 loads per thread
@@ -529,8 +536,6 @@ __global__ __launch_bounds__(256) void maxnet_cox_step_kernel(MaxnetStepParams p
       d0s[(e % BP) * MX_NS + e / BP] = v0[u];
     }
   }
-  const int xb0 = B < XB ? B : XB;
-  mx_stage(xl, xb0 * G, [&](int e) { return p.x[e]; });
   cw[(tid % MX_NS) * MX_NW + tid / MX_NS] = cshare;
   __syncthreads();
   MX_STAMP(8);
