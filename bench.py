@@ -450,15 +450,27 @@ def other_configs_leg(dev, steps, warmup, gen):
     rn = lambda *shape: torch.randn(*shape, device=dev, generator=gen)
 
     def timeit(fn, n=None):
+        """Median of three timed runs of n steps, the cyclic collector off while they run: these legs are 6-30 ms long, and one
+        generation-2 collection of a process that has built a dozen models (tens of ms) inside a single run showed up as
+        0.8 and 1.7 ms 'steps' of a 0.55 / 0.75 ms leg (two of eleven default runs at the end of round 4)."""
+        import gc
         n = n or steps
         for _ in range(max(3, warmup)):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / n
+        runs = []
+        gc.collect()
+        gc.disable()
+        try:
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                runs.append(1e3 * (time.perf_counter() - t0) / n)
+        finally:
+            gc.enable()
+        ms = sorted(runs)[1]
         return {"ms_per_step": ms, "bags_per_s": 1e3 / ms}
 
     def stepper(model, kw, loss_of, static_grads=False):
